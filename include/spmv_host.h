@@ -1,0 +1,90 @@
+/* spmv_host.h — C ABI of the host side of the MI355X SpMV engine (libspmv_host.so, plain C++/OpenMP, no HIP).
+ *
+ * These are the "either side of the kernel" pieces of the reference hot path that a drop-in needs, with the
+ * reference's exact semantics:
+ *
+ *   spmv_host_mtx_read        <- mtx_read + mtx_values_convert_to_real
+ *                                (lib/storage_formats/matrix_market/matrix_market.c:150-323,420-454; matrix_market_gen.c:65-202)
+ *   spmv_host_coo_to_csr      <- coo_to_csr(..., sort_columns=1, transpose=0)  (lib/storage_formats/csr/csr_gen.c:99-213)
+ *   spmv_host_partition_*     <- loop_partitioner_balance_iterations / _prefix_sums (lib/parallel_util.h:47-91,156-184)
+ *   spmv_host_gen_*           synthetic stand-ins for the SuiteSparse matrices of BASELINE.json (no .mtx file exists
+ *                             in the reference tree and there is no network): "twins" driven by the parameter strings of
+ *                             benchmark_code/BENCH/config.sh:402-455 (generator is OURS: the reference's generator is an
+ *                             un-vendored submodule) and an analytic nlpkkt-like KKT matrix.
+ *
+ * No SpMV arithmetic lives here: y always comes from libspmv_mi355x.so.
+ * Every function returns 0 on success; spmv_host_last_error() gives the message otherwise. Arrays handed out are
+ * malloc'ed and released with spmv_host_free().
+ */
+#ifndef SPMV_HOST_H
+#define SPMV_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char * spmv_host_last_error(void);
+void spmv_host_free(void * p);
+
+/* COO as the reference loader produces it: 0-based int32 indices, fp64 values (integer -> double, complex -> |z|,
+ * pattern -> 1.0), symmetric files expanded (entries [0,nnz_sym) = file order, then the mirrored off-diagonals in
+ * file order). */
+typedef struct {
+	long m, n, nnz, nnz_sym, nnz_diag, nnz_non_diag;
+	int  symmetric, skew, hermitian, pad_;
+	char field[16];
+	int32_t * R;
+	int32_t * C;
+	double *  V;
+} spmv_host_coo;
+
+int  spmv_host_mtx_read(const char * filename, spmv_host_coo * out);
+void spmv_host_coo_free(spmv_host_coo * coo);
+
+/* rows ascending, columns ascending inside a row, duplicates kept (in input order). row_ptr[m+1], col_idx[nnz], values[nnz]
+ * are caller-allocated. */
+int  spmv_host_coo_to_csr(const int32_t * R, const int32_t * C, const double * V, long m, long n, long nnz,
+		int32_t * row_ptr, int32_t * col_idx, double * values);
+
+/* Matrix-Market writer (coordinate real general, 1-based, %.17g) for small synthetic inputs. */
+int  spmv_host_mtx_write_csr(const char * filename, const int32_t * row_ptr, const int32_t * col_idx, const double * values,
+		long m, long n);
+
+/* worker w of W gets [*s, *e) */
+int  spmv_host_partition_iterations(long num_workers, long worker_pos, long start, long end, long * s, long * e);
+int  spmv_host_partition_prefix_sums(long num_workers, long worker_pos, const int32_t * sums, long N, long total_sum,
+		long * s, long * e);
+
+/* CSR produced by the generators */
+typedef struct {
+	long m, n, nnz;
+	int32_t * row_ptr;
+	int32_t * col_idx;
+	double *  values;
+} spmv_host_csr;
+void spmv_host_csr_free(spmv_host_csr * csr);
+
+/* Twin of a real matrix from the reference's feature vector (argument order of bench.cpp:569-579):
+ * nr_rows nr_cols avg_nnz_per_row std_nnz_per_row distribution placement avg_bw_scaled skew avg_num_neighbours
+ * cross_row_similarity seed. `pattern` != 0 -> all values 1.0 (pattern matrices), else Uniform(-1,1). */
+int  spmv_host_gen_twin(long nr_rows, long nr_cols, double avg_nnz_per_row, double std_nnz_per_row,
+		double avg_bw_scaled, double skew, double avg_num_neighbours, double cross_row_similarity,
+		unsigned long seed, int pattern, spmv_host_csr * out);
+/* Named configs of BASELINE.json: "cant", "scircuit", "pwtk", "soc-LiveJournal1", "nlpkkt240"; `scale` in (0,1] shrinks
+ * the row count (nlpkkt: the grid edge) for tests. */
+int  spmv_host_gen_named(const char * name, double scale, spmv_host_csr * out);
+/* Symmetric indefinite KKT-like matrix [H A^T; A 0] over an N^3 grid (m = 2N^3 + 6N^2, ~27.5 nnz/row; N = 240 gives
+ * the size of nlpkkt240). */
+int  spmv_host_gen_kkt(long N, unsigned long seed, spmv_host_csr * out);
+
+/* Structural features the reference uses to describe a matrix (lib/storage_formats/csr_util/csr_util_gen.c:437-447,
+ * 596-695,961): out[0..6] = avg nnz/row, std nnz/row, avg bandwidth scaled by n, skew = (max-avg)/avg,
+ * avg_num_neighbours (window 1), cross_row_similarity (window 1), max nnz/row. */
+int  spmv_host_csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out7);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,127 @@
+/* spmv_mi355x.h — C ABI of the MI355X (gfx950 / CDNA4) SpMV engine.
+ *
+ * This is the drop-in boundary for the SpMV hot path of LiHaoxu/SpMV-Research: the shared object
+ * libspmv_mi355x.so (hand-written HIP, hipcc --offload-arch=gfx950) exports exactly what a backend TU of the
+ * reference harness needs behind its plug-in API
+ *
+ *     struct Matrix_Format * csr_to_format(INT_T * row_ptr, INT_T * col_ind, ValueTypeReference * values,
+ *                                          long m, long n, long nnz, long symmetric, long symmetry_expanded);
+ *     virtual void Matrix_Format::spmv(ValueType * x, ValueType * y);
+ *         (benchmark_code/BENCH/src/spmv_kernels/spmv_kernel.h:8-29)
+ *
+ * with plain pointers, sizes and opaque handles, so the host TU is compiled by g++ with no HIP header
+ * (precedent for the split: GPU_clean/csr_rocm_vector.cpp:215,239 `extern "C" launch_kernel_wrapper`).
+ * The adapter TU that binds this ABI to Matrix_Format is spmv-research_amd/host/spmv_kernel_mi355x.cpp;
+ * INTEGRATION.md shows the Makefile_in rule a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; spmv_mi355x_last_error() gives the message
+ *     (the Matrix_Format adapter turns a failure into the reference's error()+exit behaviour, lib/debug.h:83-135);
+ *   - single caller thread per handle, blocking on return unless the name ends in _async / takes a stream;
+ *   - indices are int32 (INT_T, make.sh:166), values arrive as fp64 regardless of precision (Q3, bench.cpp:601)
+ *     and are narrowed on upload when precision == SPMV_MI355X_F32 (csr.cpp:72 does the same);
+ *   - inputs are deep-copied: the caller may free them right after create (bench.cpp:605-629);
+ *   - there is NO CPU fallback: without a usable gfx950 device create() fails.
+ */
+#ifndef SPMV_MI355X_H
+#define SPMV_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spmv_mi355x_matrix spmv_mi355x_matrix;   /* opaque */
+
+/* storage format + kernel of y = A*x */
+enum {
+	SPMV_MI355X_CSR_SCALAR   = 0,  /* one lane per row; bit-identical to the reference CPU kernel (csr.cpp:334-350)      */
+	SPMV_MI355X_CSR_VECTOR   = 1,  /* one group of 2..64 lanes per row (64 = one wavefront per row); replaces
+	                                  GPU_clean/spmv_subkernel_csr_rocm_vector.cpp:5-54 / CPU analogue csr_vec.cpp:182-213 */
+	SPMV_MI355X_CSR_MERGE    = 2,  /* merge-path CSR; replaces merge.cpp:256-319 / GPU_clean/merge_cuda.cu:249-261        */
+	SPMV_MI355X_SELL_C_SIGMA = 3,  /* sliced ELL, C rows per slice, sigma-window sort; replaces sell_sorted.cpp:112-419 /
+	                                  sell_c_s.cpp:39-131                                                                  */
+	SPMV_MI355X_COO          = 4,  /* row-sorted COO, segmented reduction; replaces mkl_coo.cpp:58-106 /
+	                                  GPU_clean/rocsparse_coo.cpp:88-104,294                                               */
+	SPMV_MI355X_NUM_FORMATS  = 5
+};
+
+enum { SPMV_MI355X_F64 = 0, SPMV_MI355X_F32 = 1 };
+
+/* Tunables. Zero-initialise, set struct_size = sizeof(spmv_mi355x_opts); 0 / unset = engine default. */
+typedef struct {
+	int  struct_size;
+	int  device;            /* HIP device ordinal; -1 = the current device                                        */
+	int  lanes_per_row;     /* CSR_VECTOR: 2,4,8,16,32,64; 0 = chosen from mean nnz/row                            */
+	int  block_threads;     /* threads per workgroup (multiple of 64); 0 = 256                                     */
+	int  sell_c;            /* SELL: rows per slice (16, 32 or 64); 0 = 64 (one wavefront = one slice)             */
+	int  sell_sigma;        /* SELL: sort window in rows (multiple of sell_c); 0 = 16384 (sell_c_s.cpp:58-60)      */
+	int  merge_items;       /* MERGE: merge items per thread (5,7,9,11,13); COO: entries per lane (2,4,8); 0 = default */
+	int  xcd_remap;         /* give each of the 8 XCDs a contiguous eighth of the tiles: 0 = auto (on), 1 = on, 2 = off */
+	int  nontemporal;       /* matrix streams loaded with the nt policy: 0 = auto (by footprint), 1 = on, 2 = off  */
+	int  reserved0;
+	long row_begin;         /* row block [row_begin,row_end) of the GLOBAL CSR to keep on this device (row-partitioned */
+	long row_end;           /*   multi-GPU, §8e); 0,0 = all rows. x stays full length n; y has row_end-row_begin rows. */
+	long col_begin;         /* optional column filter [col_begin,col_end) used for the local/remote split that lets    */
+	long col_end;           /*   the local part run while allgather(x) is in flight; 0,0 = no filter                   */
+	int  col_filter_mode;   /* 0 = keep all, 1 = keep columns inside [col_begin,col_end), 2 = keep columns outside     */
+	int  reserved1;
+} spmv_mi355x_opts;
+
+/* ---- library / device ------------------------------------------------------------------------------------ */
+const char * spmv_mi355x_last_error(void);
+int  spmv_mi355x_device_count(int * count_out);
+int  spmv_mi355x_device_info(int device, char * name_out, long name_n, int * compute_units_out, long * hbm_bytes_out);
+
+/* ---- construction = csr_to_format() (csr.cpp:221-240 and the per-format constructors) ------------------------ */
+int  spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision,
+		long m, long n, long nnz,
+		const int32_t * row_ptr, const int32_t * col_idx, const double * values_fp64,
+		const spmv_mi355x_opts * opts /* may be NULL */);
+int  spmv_mi355x_destroy(spmv_mi355x_matrix * A);
+
+/* Matrix_Format fields (spmv_kernel.h:10-15,23) */
+const char * spmv_mi355x_format_name(const spmv_mi355x_matrix * A);
+double spmv_mi355x_mem_footprint(const spmv_mi355x_matrix * A);      /* bytes of the device-side format            */
+double spmv_mi355x_csr_mem_footprint(const spmv_mi355x_matrix * A);  /* nnz*(sizeof(V)+4)+(m+1)*4                  */
+long   spmv_mi355x_rows(const spmv_mi355x_matrix * A);               /* local rows (row block)                      */
+long   spmv_mi355x_cols(const spmv_mi355x_matrix * A);
+long   spmv_mi355x_nnz(const spmv_mi355x_matrix * A);                /* local non-zeros after row/column filtering  */
+
+/* ---- Matrix_Format::spmv(x, y) with HOST buffers --------------------------------------------------------- */
+/* Reference GPU-backend semantics (GPU_clean/csr_rocm_vector.cpp:224-257): x is uploaded when the host
+ * pointer is new (or always_copy is set), one launch + device sync, y is downloaded on the first call (or when
+ * always_copy is set). x: n values, y: rows values, both of the handle's precision. */
+int  spmv_mi355x_spmv(spmv_mi355x_matrix * A, const void * x_host, void * y_host);
+int  spmv_mi355x_set_always_copy(spmv_mi355x_matrix * A, int on);   /* for callers whose x changes (bench_cg.cpp)  */
+int  spmv_mi355x_upload_x(spmv_mi355x_matrix * A, const void * x_host);
+int  spmv_mi355x_download_y(spmv_mi355x_matrix * A, void * y_host);
+
+/* ---- device-pointer entry points (solvers, multi-GPU, benchmarks) ---------------------------------------- */
+/* y_dev = A * x_dev (beta == 0) or y_dev += A * x_dev (beta == 1), enqueued on hip_stream (a hipStream_t passed
+ * as void*, NULL = the default stream); returns after enqueue. */
+int  spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x_dev, void * y_dev, int beta, void * hip_stream);
+/* Time `iters` back-to-back launches with HIP events recorded on the stream the kernels run on; ms per iteration. */
+int  spmv_mi355x_time_device(spmv_mi355x_matrix * A, const void * x_dev, void * y_dev, int iters,
+		void * hip_stream, double * ms_per_iter_out);
+/* Name and launch shape of the dominant kernel (for matching rocprofv3 kernel-trace rows). */
+int  spmv_mi355x_kernel_info(const spmv_mi355x_matrix * A, char * name_out, long name_n, long * grid_out, int * block_out);
+
+/* Device buffers owned by the handle (allocated lazily by the host-buffer entry points). */
+void * spmv_mi355x_x_device(spmv_mi355x_matrix * A);
+void * spmv_mi355x_y_device(spmv_mi355x_matrix * A);
+
+/* ---- format introspection for parity tests (host copies of the converted arrays) -------------------------- */
+/* SELL-C-sigma layout: any out pointer may be NULL. Arrays are malloc'ed copies; free with spmv_mi355x_free(). */
+int  spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma_out, long * num_slices_out,
+		long * nnz_ext_out, int64_t ** slice_ptr_out, int32_t ** col_out, double ** val_as_f64_out,
+		int32_t ** row_of_sorted_out);
+/* merge-path tile start coordinates (row, nnz) — num_tiles+1 pairs */
+int  spmv_mi355x_merge_tiles(const spmv_mi355x_matrix * A, long * num_tiles_out, long * tile_items_out, int32_t ** coords_out);
+void spmv_mi355x_free(void * p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_MI355X_H */

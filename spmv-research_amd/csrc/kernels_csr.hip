@@ -1,0 +1,182 @@
+// CSR y = A*x kernels for gfx950: one lane per row (scalar) and one group of G lanes per row (vector).
+//
+// What they replace in the reference (paths under benchmark_code/BENCH/src/spmv_kernels/):
+//   csr_scalar  : the CPU inner loop subkernel_csr_scalar (csr.cpp:334-350). One lane walks its row left to right
+//                 with one FMA per non-zero, so y is BIT-IDENTICAL to the reference CPU kernel (used as the on-device
+//                 reference for the reordering kernels).
+//   csr_vector  : "one wavefront per row" (GPU_clean/spmv_subkernel_csr_rocm_vector.cpp:5-54; CPU analogue
+//                 csr_vec.cpp:182-213), generalised to G = 2..64 lanes per row so short rows do not idle a wave64.
+//                 Lane l of a group accumulates elements l, l+G, ... (coalesced 8/4-byte streams of val/col), then a
+//                 fixed xor-butterfly over the group gives the row sum: no LDS, no atomics, every y[i] written once.
+//
+// HBM-bound: per non-zero sizeof(V)+4 bytes streamed, x gathered through L2 / Infinity Cache.
+
+#include "launch.hpp"
+
+namespace spmv {
+
+constexpr int CSR_BLOCK = 256;
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(CSR_BLOCK) void
+csr_scalar_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
+		const T * __restrict__ x, T * __restrict__ y, int m, int beta, unsigned ntiles, int remap)
+{
+	unsigned tile = xcd_tile(blockIdx.x, ntiles, remap);
+	if (tile >= ntiles)
+		return;
+	int row = tile * CSR_BLOCK + threadIdx.x;
+	if (row >= m)
+		return;
+	int j = row_ptr[row];
+	int j_e = row_ptr[row + 1];
+	T sum = 0;
+	for (; j < j_e; j++)
+		sum = fma_t<T>(ld_stream<NT>(val + j), x[ld_stream<NT>(col + j)], sum);
+	y[row] = beta ? y[row] + sum : sum;
+}
+
+template <typename T, int G, bool NT>
+__global__ __launch_bounds__(CSR_BLOCK) void
+csr_vector_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
+		const T * __restrict__ x, T * __restrict__ y, int m, int beta, unsigned ntiles, int remap)
+{
+	constexpr int ROWS_PER_BLOCK = CSR_BLOCK / G;
+	unsigned tile = xcd_tile(blockIdx.x, ntiles, remap);
+	if (tile >= ntiles)
+		return;
+	const int row = tile * ROWS_PER_BLOCK + threadIdx.x / G;
+	const int lane = threadIdx.x % G;
+	T sum = 0;
+	if (row < m)
+	{
+		const int j_s = row_ptr[row];
+		const int j_e = row_ptr[row + 1];
+		int j = j_s + lane;
+		// two independent accumulators: twice the loads in flight per lane for long rows
+		T sum2 = 0;
+		for (; j + G < j_e; j += 2 * G)
+		{
+			const int c0 = ld_stream<NT>(col + j);
+			const int c1 = ld_stream<NT>(col + j + G);
+			const T v0 = ld_stream<NT>(val + j);
+			const T v1 = ld_stream<NT>(val + j + G);
+			sum = fma_t<T>(v0, x[c0], sum);
+			sum2 = fma_t<T>(v1, x[c1], sum2);
+		}
+		if (j < j_e)
+			sum = fma_t<T>(ld_stream<NT>(val + j), x[ld_stream<NT>(col + j)], sum);
+		sum += sum2;
+	}
+	sum = group_reduce_sum<T, G>(sum);
+	if (row < m && lane == 0)
+		y[row] = beta ? y[row] + sum : sum;
+}
+
+// CSR -> COO row expansion on the device (the reference does it on the host: mkl_coo.cpp:79-90).
+__global__ __launch_bounds__(CSR_BLOCK) void
+expand_rows_kernel(const int * __restrict__ row_ptr, int m, int * __restrict__ rowind)
+{
+	// one group of 8 lanes per row: short rows dominate
+	constexpr int G = 8;
+	long row = ((long) blockIdx.x * CSR_BLOCK + threadIdx.x) / G;
+	int lane = threadIdx.x % G;
+	if (row >= m)
+		return;
+	int j_e = row_ptr[row + 1];
+	for (int j = row_ptr[row] + lane; j < j_e; j += G)
+		rowind[j] = (int) row;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+
+template <typename T>
+static int
+csr_scalar_dispatch(const int * row_ptr, const int * col, const void * val, const void * x, void * y, int m,
+		const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+{
+	unsigned ntiles = (unsigned) (((long) m + CSR_BLOCK - 1) / CSR_BLOCK);
+	unsigned grid = xcd_grid(ntiles, cfg.remap);
+	if (grid_out)
+		*grid_out = grid;
+	if (grid == 0)
+		return 0;
+	if (cfg.nt)
+		hipLaunchKernelGGL((csr_scalar_kernel<T, true>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col, (const T *) val,
+				(const T *) x, (T *) y, m, cfg.beta, ntiles, cfg.remap);
+	else
+		hipLaunchKernelGGL((csr_scalar_kernel<T, false>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col, (const T *) val,
+				(const T *) x, (T *) y, m, cfg.beta, ntiles, cfg.remap);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int
+launch_csr_scalar(bool f32, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+{
+	return f32 ? csr_scalar_dispatch<float>(row_ptr, col, val, x, y, m, cfg, stream, grid_out)
+	           : csr_scalar_dispatch<double>(row_ptr, col, val, x, y, m, cfg, stream, grid_out);
+}
+
+template <typename T, int G>
+static int
+csr_vector_launch_g(const int * row_ptr, const int * col, const void * val, const void * x, void * y, int m,
+		const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+{
+	constexpr int ROWS_PER_BLOCK = CSR_BLOCK / G;
+	unsigned ntiles = (unsigned) (((long) m + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+	unsigned grid = xcd_grid(ntiles, cfg.remap);
+	if (grid_out)
+		*grid_out = grid;
+	if (grid == 0)
+		return 0;
+	if (cfg.nt)
+		hipLaunchKernelGGL((csr_vector_kernel<T, G, true>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col,
+				(const T *) val, (const T *) x, (T *) y, m, cfg.beta, ntiles, cfg.remap);
+	else
+		hipLaunchKernelGGL((csr_vector_kernel<T, G, false>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col,
+				(const T *) val, (const T *) x, (T *) y, m, cfg.beta, ntiles, cfg.remap);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+template <typename T>
+static int
+csr_vector_dispatch(int G, const int * row_ptr, const int * col, const void * val, const void * x, void * y, int m,
+		const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+{
+	switch (G)
+	{
+		case 2:  return csr_vector_launch_g<T, 2>(row_ptr, col, val, x, y, m, cfg, stream, grid_out);
+		case 4:  return csr_vector_launch_g<T, 4>(row_ptr, col, val, x, y, m, cfg, stream, grid_out);
+		case 8:  return csr_vector_launch_g<T, 8>(row_ptr, col, val, x, y, m, cfg, stream, grid_out);
+		case 16: return csr_vector_launch_g<T, 16>(row_ptr, col, val, x, y, m, cfg, stream, grid_out);
+		case 32: return csr_vector_launch_g<T, 32>(row_ptr, col, val, x, y, m, cfg, stream, grid_out);
+		case 64: return csr_vector_launch_g<T, 64>(row_ptr, col, val, x, y, m, cfg, stream, grid_out);
+	}
+	set_error("csr_vector: lanes_per_row must be 2,4,8,16,32 or 64 (got %d)", G);
+	return 1;
+}
+
+int
+launch_csr_vector(bool f32, int lanes_per_row, const int * row_ptr, const int * col, const void * val,
+		const void * x, void * y, int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+{
+	return f32 ? csr_vector_dispatch<float>(lanes_per_row, row_ptr, col, val, x, y, m, cfg, stream, grid_out)
+	           : csr_vector_dispatch<double>(lanes_per_row, row_ptr, col, val, x, y, m, cfg, stream, grid_out);
+}
+
+int
+launch_expand_rows(const int * row_ptr, int m, int * rowind, hipStream_t stream)
+{
+	if (m <= 0)
+		return 0;
+	long threads = (long) m * 8;
+	unsigned grid = (unsigned) ((threads + CSR_BLOCK - 1) / CSR_BLOCK);
+	hipLaunchKernelGGL(expand_rows_kernel, dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, m, rowind);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+}  // namespace spmv

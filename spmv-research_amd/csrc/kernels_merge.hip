@@ -1,0 +1,315 @@
+// Merge-path CSR SpMV for gfx950 (Merrill & Garland's formulation, as the reference uses it on the CPU:
+// benchmark_code/BENCH/src/spmv_kernels/merge.cpp:226-319; CUDA comparator GPU_clean/merge_cuda.cu:249-261).
+//
+// The (m + nnz)-long merge path over (row end offsets, non-zero indices) is cut into tiles of TILE = 256*IPT items.
+// Tile start coordinates depend only on row_ptr, so they are searched ONCE at format-conversion time
+// (merge_search_kernel) instead of on every SpMV as the generic CUB dispatch does.
+//
+// Per tile (one workgroup of 256 threads = 4 wavefronts):
+//   1. coalesced loads: the tile's row end offsets -> LDS; the tile's non-zeros val[j]*x[col[j]] -> LDS (each thread
+//      issues all IPT val/col loads before the first dependent x gather: ~IPT*(sizeof(V)+4) bytes in flight per lane);
+//   2. every thread binary-searches its own diagonal in LDS and consumes exactly IPT merge items (perfect balance
+//      for power-law rows): rows that end inside a thread are stored at once;
+//   3. the partial sum a thread carries out of / into its first row is resolved by ONE segmented scan over the
+//      workgroup (wave shuffles + 4-entry LDS hand-off);
+//   4. the tile's last partial row goes to (carry_row, carry_val)[tile]; merge_fixup_kernel adds the carries in tile
+//      order (sequential inside a run of equal rows) -> the result is reproducible run to run.
+//
+// Every y[i] is written exactly once by the main kernel (empty rows get 0) and touched again only if a row
+// crosses a tile boundary. fp64/fp32: products are rounded once (v*x) and added in merge order.
+
+#include "launch.hpp"
+
+namespace spmv {
+
+constexpr int MERGE_BLOCK = 256;
+
+__host__ __device__ inline void
+merge_path_search(int diagonal, const int * __restrict__ row_end, int a_len, int b_len, int b_offset, int * x_out, int * y_out)
+{
+	// list A = row_end[0..a_len) (absolute nnz offsets), list B = b_offset + (0..b_len)
+	int x_min = diagonal - b_len;
+	if (x_min < 0)
+		x_min = 0;
+	int x_max = diagonal < a_len ? diagonal : a_len;
+	while (x_min < x_max)
+	{
+		int pivot = (x_min + x_max) >> 1;
+		if (row_end[pivot] <= b_offset + diagonal - pivot - 1)
+			x_min = pivot + 1;
+		else
+			x_max = pivot;
+	}
+	*x_out = x_min < a_len ? x_min : a_len;
+	*y_out = diagonal - x_min;
+}
+
+// one thread per tile boundary; coords[2*t] = row, coords[2*t+1] = nnz index
+__global__ __launch_bounds__(MERGE_BLOCK) void
+merge_search_kernel(const int * __restrict__ row_ptr, int m, int nnz, int tile_items, int num_tiles, int * __restrict__ coords)
+{
+	int t = blockIdx.x * MERGE_BLOCK + threadIdx.x;
+	if (t > num_tiles)
+		return;
+	long total = (long) m + nnz;
+	long d = (long) t * tile_items;
+	if (d > total)
+		d = total;
+	int rx, ry;
+	merge_path_search((int) d, row_ptr + 1, m, nnz, 0, &rx, &ry);
+	coords[2 * t] = rx;
+	coords[2 * t + 1] = ry;
+}
+
+template <typename T, int IPT, bool NT>
+__global__ __launch_bounds__(MERGE_BLOCK) void
+merge_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
+		const T * __restrict__ x, T * __restrict__ y, int m, const int * __restrict__ coords,
+		int * __restrict__ carry_row, T * __restrict__ carry_val, int beta, unsigned ntiles, int remap)
+{
+	constexpr int TILE = MERGE_BLOCK * IPT;
+	// rows_in_tile + nnz_in_tile <= TILE: products first, row ends behind them, in one buffer
+	__shared__ __attribute__((aligned(16))) unsigned char s_buf[TILE * sizeof(T) + 16];
+	__shared__ T s_wave_val[MERGE_BLOCK / WAVE];
+	__shared__ int s_wave_flag[MERGE_BLOCK / WAVE];
+
+	const unsigned tile = xcd_tile(blockIdx.x, ntiles, remap);
+	if (tile >= ntiles)
+		return;
+	const int tid = threadIdx.x;
+	const int * __restrict__ row_end = row_ptr + 1;
+
+	const int row0 = coords[2 * tile], nz0 = coords[2 * tile + 1];
+	const int row1 = coords[2 * tile + 2], nz1 = coords[2 * tile + 3];
+	const int tile_rows = row1 - row0;
+	const int tile_nnz = nz1 - nz0;
+	const int tile_items = tile_rows + tile_nnz;
+
+	T * s_prod = reinterpret_cast<T *>(s_buf);
+	int * s_row_end = reinterpret_cast<int *>(s_buf + (size_t) tile_nnz * sizeof(T));   // 4-byte aligned for both T
+
+	// ---- 1. stage the tile
+	{
+		int c[IPT];
+		T v[IPT];
+		#pragma unroll
+		for (int k = 0; k < IPT; k++)
+		{
+			int idx = tid + k * MERGE_BLOCK;
+			bool ok = idx < tile_nnz;
+			long j = (long) nz0 + (ok ? idx : 0);
+			c[k] = ok ? ld_stream<NT>(col + j) : 0;
+			v[k] = ok ? ld_stream<NT>(val + j) : T(0);
+		}
+		for (int idx = tid; idx < tile_rows; idx += MERGE_BLOCK)
+			s_row_end[idx] = row_end[row0 + idx];
+		#pragma unroll
+		for (int k = 0; k < IPT; k++)
+		{
+			int idx = tid + k * MERGE_BLOCK;
+			if (idx < tile_nnz)
+				s_prod[idx] = v[k] * x[c[k]];
+		}
+	}
+	__syncthreads();
+
+	// ---- 2. per-thread merge path segment
+	int diag = tid * IPT;
+	if (diag > tile_items)
+		diag = tile_items;
+	int r, k;
+	merge_path_search(diag, s_row_end, tile_rows, tile_nnz, nz0, &r, &k);
+
+	T running = 0;
+	bool had_end = false;
+	int first_row = 0;
+	T first_val = 0;
+	int next_end = (r < tile_rows) ? s_row_end[r] : 0x7fffffff;
+	#pragma unroll
+	for (int it = 0; it < IPT; it++)
+	{
+		if (diag + it < tile_items)
+		{
+			if (nz0 + k < next_end)
+			{
+				running += s_prod[k];
+				k++;
+			}
+			else
+			{
+				if (!had_end)
+				{
+					had_end = true;
+					first_row = r;
+					first_val = running;
+				}
+				else
+				{
+					T * yp = y + (row0 + r);
+					*yp = beta ? *yp + running : running;
+				}
+				running = 0;
+				r++;
+				next_end = (r < tile_rows) ? s_row_end[r] : 0x7fffffff;
+			}
+		}
+	}
+
+	// ---- 3. segmented inclusive scan of (had_end, running) over the workgroup.
+	//         (f1,v1) (+) (f2,v2) = (f1|f2, f2 ? v2 : v1+v2)
+	const int lane = tid % WAVE;
+	const int wave = tid / WAVE;
+	int f = had_end ? 1 : 0;
+	T v = running;
+	#pragma unroll
+	for (int off = 1; off < WAVE; off <<= 1)
+	{
+		int fo = __shfl_up(f, off, WAVE);
+		T vo = shfl_up_t(v, off);
+		if (lane >= off)
+		{
+			v = f ? v : vo + v;
+			f |= fo;
+		}
+	}
+	if (lane == WAVE - 1)
+	{
+		s_wave_val[wave] = v;
+		s_wave_flag[wave] = f;
+	}
+	// exclusive value inside the wave
+	T ex_v = shfl_up_t(v, 1);
+	int ex_f = __shfl_up(f, 1, WAVE);
+	if (lane == 0)
+	{
+		ex_v = 0;
+		ex_f = 0;
+	}
+	__syncthreads();
+	// prefix of the earlier waves
+	T pv = 0;
+	for (int w = 0; w < wave; w++)
+	{
+		T wv = s_wave_val[w];
+		pv = s_wave_flag[w] ? wv : pv + wv;
+	}
+	// carry into this thread = prefix (+) exclusive-in-wave
+	const T carry_in = ex_f ? ex_v : pv + ex_v;
+
+	if (had_end)
+	{
+		T * yp = y + (row0 + first_row);
+		T out = carry_in + first_val;
+		*yp = beta ? *yp + out : out;
+	}
+	if (tid == MERGE_BLOCK - 1)
+	{
+		// inclusive value of the last thread = partial sum of the row still open at the end of the tile
+		T total = f ? v : pv + v;
+		carry_row[tile] = row1;
+		carry_val[tile] = total;
+	}
+}
+
+// Adds the tile carries to y. Carries are ordered by row (tile order); the thread owning the first carry of a run of
+// equal rows sums the run sequentially -> deterministic.
+template <typename T>
+__global__ __launch_bounds__(MERGE_BLOCK) void
+merge_fixup_kernel(const int * __restrict__ carry_row, const T * __restrict__ carry_val, int ncarry, int m, T * __restrict__ y)
+{
+	int t = blockIdx.x * MERGE_BLOCK + threadIdx.x;
+	if (t >= ncarry)
+		return;
+	int row = carry_row[t];
+	if (row >= m || row < 0)
+		return;
+	if (t > 0 && carry_row[t - 1] == row)
+		return;
+	T sum = carry_val[t];
+	for (int u = t + 1; u < ncarry && carry_row[u] == row; u++)
+		sum += carry_val[u];
+	y[row] += sum;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+
+static int
+merge_default_ipt(bool f32, int items_per_thread)
+{
+	// odd counts only: thread t starts reading LDS products near t*IPT, and an odd stride maps the 64 lanes of a
+	// ds_read onto distinct banks (even strides give up to 8-way conflicts)
+	if (items_per_thread == 5 || items_per_thread == 7 || items_per_thread == 9 || items_per_thread == 11 || items_per_thread == 13)
+		return items_per_thread;
+	(void) f32;
+	return 7;
+}
+
+int
+merge_tile_items(bool f32, int items_per_thread)
+{
+	return MERGE_BLOCK * merge_default_ipt(f32, items_per_thread);
+}
+
+int
+launch_merge_search(const int * row_ptr, int m, int nnz, int tile_items, int num_tiles, int * coords, hipStream_t stream)
+{
+	unsigned grid = (unsigned) ((num_tiles + 1 + MERGE_BLOCK - 1) / MERGE_BLOCK);
+	hipLaunchKernelGGL(merge_search_kernel, dim3(grid), dim3(MERGE_BLOCK), 0, stream, row_ptr, m, nnz, tile_items, num_tiles, coords);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+template <typename T, int IPT>
+static int
+merge_launch_ipt(const int * row_ptr, const int * col, const void * val, const void * x, void * y, int m, int num_tiles,
+		const int * coords, int * carry_row, void * carry_val, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+{
+	unsigned ntiles = (unsigned) num_tiles;
+	unsigned grid = xcd_grid(ntiles, cfg.remap);
+	if (grid_out)
+		*grid_out = grid;
+	if (grid == 0)
+		return 0;
+	if (cfg.nt)
+		hipLaunchKernelGGL((merge_kernel<T, IPT, true>), dim3(grid), dim3(MERGE_BLOCK), 0, stream, row_ptr, col, (const T *) val,
+				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, ntiles, cfg.remap);
+	else
+		hipLaunchKernelGGL((merge_kernel<T, IPT, false>), dim3(grid), dim3(MERGE_BLOCK), 0, stream, row_ptr, col, (const T *) val,
+				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, ntiles, cfg.remap);
+	HIP_TRY(hipGetLastError());
+	unsigned fgrid = (ntiles + MERGE_BLOCK - 1) / MERGE_BLOCK;
+	hipLaunchKernelGGL((merge_fixup_kernel<T>), dim3(fgrid), dim3(MERGE_BLOCK), 0, stream, carry_row, (const T *) carry_val,
+			(int) ntiles, m, (T *) y);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+template <typename T>
+static int
+merge_dispatch(int ipt, const int * row_ptr, const int * col, const void * val, const void * x, void * y, int m, int num_tiles,
+		const int * coords, int * carry_row, void * carry_val, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+{
+	switch (ipt)
+	{
+		case 5:  return merge_launch_ipt<T, 5>(row_ptr, col, val, x, y, m, num_tiles, coords, carry_row, carry_val, cfg, stream, grid_out);
+		case 7:  return merge_launch_ipt<T, 7>(row_ptr, col, val, x, y, m, num_tiles, coords, carry_row, carry_val, cfg, stream, grid_out);
+		case 9:  return merge_launch_ipt<T, 9>(row_ptr, col, val, x, y, m, num_tiles, coords, carry_row, carry_val, cfg, stream, grid_out);
+		case 11: return merge_launch_ipt<T, 11>(row_ptr, col, val, x, y, m, num_tiles, coords, carry_row, carry_val, cfg, stream, grid_out);
+		case 13: return merge_launch_ipt<T, 13>(row_ptr, col, val, x, y, m, num_tiles, coords, carry_row, carry_val, cfg, stream, grid_out);
+	}
+	set_error("merge: unsupported items per thread %d", ipt);
+	return 1;
+}
+
+int
+launch_merge(bool f32, int items_per_thread, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+		int m, int nnz, int num_tiles, const int * coords, int * carry_row, void * carry_val,
+		const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+{
+	(void) nnz;
+	int ipt = merge_default_ipt(f32, items_per_thread);
+	return f32 ? merge_dispatch<float>(ipt, row_ptr, col, val, x, y, m, num_tiles, coords, carry_row, carry_val, cfg, stream, grid_out)
+	           : merge_dispatch<double>(ipt, row_ptr, col, val, x, y, m, num_tiles, coords, carry_row, carry_val, cfg, stream, grid_out);
+}
+
+}  // namespace spmv

@@ -1,0 +1,42 @@
+// Host-callable launchers of the HIP kernels (one translation unit per kernel family).
+// All launchers enqueue on `stream` and return 0 / 1 (error text via spmv::set_error). `f32` selects float.
+#pragma once
+
+#include "common.hpp"
+
+namespace spmv {
+
+struct LaunchCfg {
+	int remap;          // XCD-aware tile order
+	int nt;             // nontemporal matrix streams
+	int beta;           // 0: y = A x, 1: y += A x
+};
+
+// ---- CSR (kernels_csr.hip)
+int launch_csr_scalar(bool f32, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+int launch_csr_vector(bool f32, int lanes_per_row, const int * row_ptr, const int * col, const void * val,
+		const void * x, void * y, int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+
+// ---- merge-path CSR (kernels_merge.hip)
+int merge_tile_items(bool f32, int items_per_thread);                 // merge items (rows + nnz) per workgroup
+int launch_merge_search(const int * row_ptr, int m, int nnz, int tile_items, int num_tiles, int * coords /* [2*(num_tiles+1)] */,
+		hipStream_t stream);
+int launch_merge(bool f32, int items_per_thread, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+		int m, int nnz, int num_tiles, const int * coords, int * carry_row, void * carry_val,
+		const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+
+// ---- SELL-C-sigma (kernels_sell.hip)
+int launch_sell(bool f32, int C, const int64_t * slice_ptr, const int * col, const void * val, const int * row_of_sorted,
+		const void * x, void * y, int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+
+// ---- COO (kernels_coo.hip)
+int coo_wave_items(int items_per_lane);                                // entries per wavefront
+int launch_coo(bool f32, int items_per_lane, const int * rowind, const int * col, const void * val, const void * x, void * y,
+		int m, long nnz, int num_waves, int * carry_row, void * carry_val,
+		const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+
+// ---- small utility kernels (kernels_csr.hip)
+int launch_expand_rows(const int * row_ptr, int m, int * rowind, hipStream_t stream);   // CSR -> COO row indices (mkl_coo.cpp:79-90)
+
+}  // namespace spmv

@@ -1,0 +1,803 @@
+// C ABI of the MI355X SpMV engine (include/spmv_mi355x.h): handle management, format conversion
+// (= the reference's csr_to_format constructors) and the spmv entry points. Host code only; the kernels live in
+// kernels_*.hip. There is deliberately NO CPU compute path here: every y comes from a HIP kernel.
+
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <math.h>
+#include <algorithm>
+#include <numeric>
+#include <vector>
+#include <omp.h>
+
+#include "../../include/spmv_mi355x.h"
+#include "launch.hpp"
+
+namespace spmv {
+
+static thread_local char g_err[1024] = "";
+
+void
+set_error(const char * fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+}  // namespace spmv
+
+using namespace spmv;
+
+struct spmv_mi355x_matrix {
+	int format = 0, precision = 0;
+	long m = 0, n = 0, nnz = 0;            // local rows, columns, local non-zeros
+	int device = 0;
+	bool f32 = false;
+	size_t vbytes = 8;
+	LaunchCfg cfg{1, 0, 0};
+
+	// CSR family
+	int * d_row_ptr = nullptr;
+	int * d_col = nullptr;
+	void * d_val = nullptr;
+	int lanes_per_row = 0;
+	// merge
+	int merge_ipt = 0, merge_tile = 0, merge_num_tiles = 0;
+	int * d_coords = nullptr;
+	int * d_carry_row = nullptr;
+	void * d_carry_val = nullptr;
+	// SELL
+	int sell_c = 0;
+	long sell_sigma = 0, sell_slices = 0, sell_nnz_ext = 0;
+	int64_t * d_slice_ptr = nullptr;
+	int * d_row_of_sorted = nullptr;
+	// COO
+	int coo_k = 0, coo_num_waves = 0;
+	int * d_rowind = nullptr;
+
+	// host-buffer path
+	void * d_x = nullptr;
+	void * d_y = nullptr;
+	const void * cached_x_host = nullptr;
+	bool y_downloaded = false;
+	bool always_copy = false;
+	hipStream_t stream = nullptr;
+
+	double mem_footprint = 0, csr_mem_footprint = 0;
+	char format_name[96] = "";
+	char kernel_name[64] = "";
+	long last_grid = 0;
+};
+
+template <typename T>
+static int
+dev_alloc(T ** p, size_t count)
+{
+	*p = nullptr;
+	if (count == 0)
+		count = 1;
+	HIP_TRY(hipMalloc((void **) p, count * sizeof(T)));
+	return 0;
+}
+
+static int
+dev_alloc_bytes(void ** p, size_t bytes)
+{
+	*p = nullptr;
+	if (bytes == 0)
+		bytes = 8;
+	HIP_TRY(hipMalloc(p, bytes));
+	return 0;
+}
+
+static void
+free_all(spmv_mi355x_matrix * A)
+{
+	void * ptrs[] = {A->d_row_ptr, A->d_col, A->d_val, A->d_coords, A->d_carry_row, A->d_carry_val, A->d_slice_ptr,
+	                 A->d_row_of_sorted, A->d_rowind, A->d_x, A->d_y};
+	for (void * p : ptrs)
+		if (p)
+			(void) hipFree(p);
+	if (A->stream)
+		(void) hipStreamDestroy(A->stream);
+}
+
+// narrow fp64 reference values to the handle's precision (csr.cpp:72 `a[i] = values[i]`) and upload
+static int
+upload_values(spmv_mi355x_matrix * A, const double * v, size_t count, void ** d_out)
+{
+	if (dev_alloc_bytes(d_out, count * A->vbytes))
+		return 1;
+	if (count == 0)
+		return 0;
+	if (!A->f32)
+	{
+		HIP_TRY(hipMemcpy(*d_out, v, count * sizeof(double), hipMemcpyHostToDevice));
+		return 0;
+	}
+	// chunked narrowing keeps the host staging buffer small for 10^9-entry matrices
+	const size_t CH = (size_t) 1 << 26;
+	std::vector<float> tmp(std::min(CH, count));
+	for (size_t off = 0; off < count; off += CH)
+	{
+		size_t len = std::min(CH, count - off);
+		#pragma omp parallel for
+		for (long i = 0; i < (long) len; i++)
+			tmp[i] = (float) v[off + i];
+		HIP_TRY(hipMemcpy((char *) *d_out + off * sizeof(float), tmp.data(), len * sizeof(float), hipMemcpyHostToDevice));
+	}
+	return 0;
+}
+
+static int
+upload_ints(const int * src, size_t count, int ** d_out)
+{
+	if (dev_alloc(d_out, count))
+		return 1;
+	if (count)
+		HIP_TRY(hipMemcpy(*d_out, src, count * sizeof(int), hipMemcpyHostToDevice));
+	return 0;
+}
+
+static int
+pick_lanes_per_row(double mean)
+{
+	if (mean <= 3) return 2;
+	if (mean <= 6) return 4;
+	if (mean <= 12) return 8;
+	if (mean <= 24) return 16;
+	if (mean <= 48) return 32;
+	return 64;
+}
+
+// ---------------------------------------------------------------------------------------------------- SELL build
+// Host-side CSR -> SELL-C-sigma (the reference converts on the host too: sell_sorted.cpp:112-298, sellcs_format.c:137-200).
+// Window sort: stable, DESCENDING row length inside each window of sigma rows (radix_sort.c:103-122 semantics).
+static int
+build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va)
+{
+	const long m = A->m;
+	const int C = A->sell_c;
+	const int TPR = WAVE / C;
+	const long sigma = A->sell_sigma;
+	const long num_slices = (m + C - 1) / C;
+	std::vector<int> row_of_sorted(std::max<long>(m, 1));
+	const long num_windows = (m + sigma - 1) / sigma;
+	#pragma omp parallel for schedule(dynamic, 4)
+	for (long w = 0; w < num_windows; w++)
+	{
+		long s = w * sigma, e = std::min(m, s + sigma);
+		// counting sort by length, descending, stable
+		int maxlen = 0;
+		for (long i = s; i < e; i++)
+			maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
+		std::vector<long> cnt((size_t) maxlen + 2, 0);
+		for (long i = s; i < e; i++)
+			cnt[maxlen - (rp[i + 1] - rp[i]) + 1]++;
+		for (int b = 0; b <= maxlen; b++)
+			cnt[b + 1] += cnt[b];
+		for (long i = s; i < e; i++)
+			row_of_sorted[s + cnt[maxlen - (rp[i + 1] - rp[i])]++] = (int) i;
+	}
+	std::vector<int64_t> slice_ptr((size_t) num_slices + 1, 0);
+	#pragma omp parallel for
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		long width = 0;
+		for (long i = sl * C; i < std::min(m, (sl + 1) * C); i++)
+		{
+			int o = row_of_sorted[i];
+			width = std::max<long>(width, rp[o + 1] - rp[o]);
+		}
+		width = (width + TPR - 1) / TPR * TPR;
+		slice_ptr[sl + 1] = width * C;
+	}
+	for (long sl = 0; sl < num_slices; sl++)
+		slice_ptr[sl + 1] += slice_ptr[sl];
+	const int64_t nnz_ext = slice_ptr[num_slices];
+	std::vector<int> col((size_t) std::max<int64_t>(nnz_ext, 1));
+	std::vector<double> val((size_t) std::max<int64_t>(nnz_ext, 1));
+	#pragma omp parallel for schedule(dynamic, 64)
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		const int64_t base = slice_ptr[sl];
+		const long width = (slice_ptr[sl + 1] - base) / C;
+		for (int r = 0; r < C; r++)
+		{
+			long i = sl * C + r;
+			long js = 0, len = 0;
+			if (i < m)
+			{
+				int o = row_of_sorted[i];
+				js = rp[o];
+				len = rp[o + 1] - rp[o];
+			}
+			// padding: value 0 times a column this row already touches (keeps the gather in cache; the reference pads
+			// with the last real column as well, sell_sorted.cpp:280-284)
+			int pad_col = len > 0 ? ci[js + len - 1] : 0;
+			for (long k = 0; k < width; k++)
+			{
+				int64_t p = base + k * C + r;
+				if (k < len)
+				{
+					col[p] = ci[js + k];
+					val[p] = va[js + k];
+				}
+				else
+				{
+					col[p] = pad_col;
+					val[p] = 0.0;
+				}
+			}
+		}
+	}
+	A->sell_slices = num_slices;
+	A->sell_nnz_ext = nnz_ext;
+	if (dev_alloc(&A->d_slice_ptr, (size_t) num_slices + 1))
+		return 1;
+	HIP_TRY(hipMemcpy(A->d_slice_ptr, slice_ptr.data(), ((size_t) num_slices + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+	if (upload_ints(col.data(), (size_t) nnz_ext, &A->d_col))
+		return 1;
+	if (upload_values(A, val.data(), (size_t) nnz_ext, &A->d_val))
+		return 1;
+	if (upload_ints(row_of_sorted.data(), (size_t) m, &A->d_row_of_sorted))
+		return 1;
+	// (num_slices+1) offsets + padded entries + the row permutation (cf. sell_sorted.cpp:297)
+	A->mem_footprint = (double) (num_slices + 1) * sizeof(int64_t) + (double) nnz_ext * (A->vbytes + 4) + (double) m * 4;
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- C ABI
+
+extern "C" {
+
+const char *
+spmv_mi355x_last_error(void)
+{
+	return g_err;
+}
+
+int
+spmv_mi355x_device_count(int * count_out)
+{
+	int c = 0;
+	hipError_t e = hipGetDeviceCount(&c);
+	if (e != hipSuccess)
+	{
+		(void) hipGetLastError();
+		c = 0;
+	}
+	*count_out = c;
+	return 0;
+}
+
+int
+spmv_mi355x_device_info(int device, char * name_out, long name_n, int * compute_units_out, long * hbm_bytes_out)
+{
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if (name_out && name_n > 0)
+		snprintf(name_out, name_n, "%s (%s)", prop.name, prop.gcnArchName);
+	if (compute_units_out)
+		*compute_units_out = prop.multiProcessorCount;
+	if (hbm_bytes_out)
+		*hbm_bytes_out = (long) prop.totalGlobalMem;
+	return 0;
+}
+
+int
+spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m, long n, long nnz,
+		const int32_t * row_ptr, const int32_t * col_idx, const double * values, const spmv_mi355x_opts * opts_in)
+{
+	*out = nullptr;
+	spmv_mi355x_opts o;
+	memset(&o, 0, sizeof(o));
+	o.device = -1;
+	if (opts_in)
+	{
+		size_t sz = std::min<size_t>(sizeof(o), (size_t) std::max(opts_in->struct_size, 0));
+		if (sz < 8)
+		{
+			set_error("opts->struct_size not set");
+			return 1;
+		}
+		memcpy(&o, opts_in, sz);
+	}
+	if (format < 0 || format >= SPMV_MI355X_NUM_FORMATS)
+	{
+		set_error("unknown format %d", format);
+		return 1;
+	}
+	if (precision != SPMV_MI355X_F64 && precision != SPMV_MI355X_F32)
+	{
+		set_error("unknown precision %d", precision);
+		return 1;
+	}
+	if (m < 0 || n < 0 || nnz < 0 || m >= 0x7fffffffL || n >= 0x7fffffffL || nnz >= 0x7fffffffL || m + nnz >= 0x7fffffffL)
+	{
+		set_error("sizes out of the int32 index range (m=%ld n=%ld nnz=%ld)", m, n, nnz);
+		return 1;
+	}
+	if (!row_ptr || (nnz > 0 && (!col_idx || !values)))
+	{
+		set_error("NULL input array");
+		return 1;
+	}
+	if (row_ptr[m] - row_ptr[0] != nnz)
+	{
+		set_error("row_ptr[m]-row_ptr[0] = %ld does not match nnz = %ld", (long) (row_ptr[m] - row_ptr[0]), nnz);
+		return 1;
+	}
+	int ndev = 0;
+	spmv_mi355x_device_count(&ndev);
+	if (ndev < 1)
+	{
+		set_error("no HIP device available: this engine has no CPU fallback");
+		return 1;
+	}
+	int device = o.device;
+	if (device < 0)
+		HIP_TRY(hipGetDevice(&device));
+	if (device >= ndev)
+	{
+		set_error("device %d out of range (%d devices)", device, ndev);
+		return 1;
+	}
+	HIP_TRY(hipSetDevice(device));
+
+	spmv_mi355x_matrix * A = new spmv_mi355x_matrix();
+	A->format = format;
+	A->precision = precision;
+	A->f32 = (precision == SPMV_MI355X_F32);
+	A->vbytes = A->f32 ? 4 : 8;
+	A->device = device;
+	A->n = n;
+
+	// ---- row block / column filter (row-partitioned multi-GPU) -> local CSR on the host
+	long r0 = o.row_begin, r1 = o.row_end;
+	if (r0 == 0 && r1 == 0)
+		r1 = m;
+	if (r0 < 0 || r1 > m || r0 > r1)
+	{
+		set_error("bad row block [%ld,%ld) for m=%ld", r0, r1, m);
+		delete A;
+		return 1;
+	}
+	const long lm = r1 - r0;
+	std::vector<int> l_rp;
+	std::vector<int> l_ci;
+	std::vector<double> l_va;
+	const int * rp;
+	const int * ci;
+	const double * va;
+	long lnnz;
+	const bool filter = o.col_filter_mode == 1 || o.col_filter_mode == 2;
+	if (!filter && row_ptr[r0] == 0)
+	{
+		rp = row_ptr + r0;     // [0, r1) prefix: offsets are already local
+		ci = col_idx;
+		va = values;
+		lnnz = row_ptr[r1];
+	}
+	else
+	{
+		l_rp.assign((size_t) lm + 1, 0);
+		const long c0 = o.col_begin, c1 = o.col_end;
+		const bool inside = o.col_filter_mode == 1;
+		#pragma omp parallel for
+		for (long i = 0; i < lm; i++)
+		{
+			int cnt = 0;
+			if (!filter)
+				cnt = row_ptr[r0 + i + 1] - row_ptr[r0 + i];
+			else
+				for (long j = row_ptr[r0 + i]; j < row_ptr[r0 + i + 1]; j++)
+				{
+					bool in = col_idx[j] >= c0 && col_idx[j] < c1;
+					cnt += (in == inside);
+				}
+			l_rp[i + 1] = cnt;
+		}
+		for (long i = 0; i < lm; i++)
+			l_rp[i + 1] += l_rp[i];
+		lnnz = l_rp[lm];
+		l_ci.resize((size_t) std::max<long>(lnnz, 1));
+		l_va.resize((size_t) std::max<long>(lnnz, 1));
+		#pragma omp parallel for
+		for (long i = 0; i < lm; i++)
+		{
+			long k = l_rp[i];
+			for (long j = row_ptr[r0 + i]; j < row_ptr[r0 + i + 1]; j++)
+			{
+				if (filter)
+				{
+					bool in = col_idx[j] >= c0 && col_idx[j] < c1;
+					if (in != inside)
+						continue;
+				}
+				l_ci[k] = col_idx[j];
+				l_va[k] = values[j];
+				k++;
+			}
+		}
+		rp = l_rp.data();
+		ci = l_ci.data();
+		va = l_va.data();
+	}
+	A->m = lm;
+	A->nnz = lnnz;
+	A->csr_mem_footprint = (double) lnnz * (A->vbytes + 4) + (double) (lm + 1) * 4;
+	// full validation before anything reaches a kernel: an out-of-range index would be an out-of-bounds device read
+	{
+		long bad_col = -1, bad_row = -1;
+		#pragma omp parallel for reduction(max : bad_col)
+		for (long j = 0; j < lnnz; j++)
+			if (ci[j] < 0 || ci[j] >= n)
+				bad_col = std::max(bad_col, j);
+		#pragma omp parallel for reduction(max : bad_row)
+		for (long i = 0; i < lm; i++)
+			if (rp[i + 1] < rp[i])
+				bad_row = std::max(bad_row, i);
+		if (bad_col >= 0 || bad_row >= 0 || (lm > 0 && rp[0] != 0 && !l_rp.empty()))
+		{
+			if (bad_col >= 0)
+				set_error("column index %d out of range [0,%ld) at entry %ld", ci[bad_col], n, bad_col);
+			else
+				set_error("row_ptr is not monotone at row %ld", bad_row);
+			delete A;
+			return 1;
+		}
+	}
+
+	// ---- launch policy
+	A->cfg.remap = (o.xcd_remap == 2) ? 0 : 1;
+	const double stream_bytes = (double) lnnz * (A->vbytes + 4);
+	A->cfg.nt = (o.nontemporal == 1) ? 1 : (o.nontemporal == 2) ? 0 : (stream_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
+	A->cfg.beta = 0;
+
+	int rc = 0;
+	const char * pf = A->f32 ? "f" : "d";
+	switch (format)
+	{
+		case SPMV_MI355X_CSR_SCALAR:
+		case SPMV_MI355X_CSR_VECTOR:
+		case SPMV_MI355X_CSR_MERGE:
+		{
+			rc = upload_ints(rp, (size_t) lm + 1, &A->d_row_ptr) || upload_ints(ci, (size_t) lnnz, &A->d_col) ||
+			     upload_values(A, va, (size_t) lnnz, &A->d_val);
+			if (rc)
+				break;
+			A->mem_footprint = A->csr_mem_footprint;
+			if (format == SPMV_MI355X_CSR_SCALAR)
+			{
+				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_SCALAR_%s", pf);
+				snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_scalar_kernel");
+			}
+			else if (format == SPMV_MI355X_CSR_VECTOR)
+			{
+				int G = o.lanes_per_row;
+				if (G == 0)
+					G = pick_lanes_per_row(lm > 0 ? (double) lnnz / lm : 0);
+				if (G != 2 && G != 4 && G != 8 && G != 16 && G != 32 && G != 64)
+				{
+					set_error("lanes_per_row must be 2,4,8,16,32 or 64 (got %d)", G);
+					rc = 1;
+					break;
+				}
+				A->lanes_per_row = G;
+				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_VECTOR_g%d_%s", G, pf);
+				snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_vector_kernel");
+			}
+			else
+			{
+				A->merge_ipt = o.merge_items;
+				A->merge_tile = merge_tile_items(A->f32, A->merge_ipt);
+				A->merge_ipt = A->merge_tile / 256;
+				long total = lm + lnnz;
+				A->merge_num_tiles = (int) ((total + A->merge_tile - 1) / A->merge_tile);
+				rc = dev_alloc(&A->d_coords, 2 * ((size_t) A->merge_num_tiles + 1)) ||
+				     dev_alloc(&A->d_carry_row, (size_t) A->merge_num_tiles) ||
+				     dev_alloc_bytes(&A->d_carry_val, (size_t) A->merge_num_tiles * A->vbytes);
+				if (rc)
+					break;
+				rc = launch_merge_search(A->d_row_ptr, (int) lm, (int) lnnz, A->merge_tile, A->merge_num_tiles, A->d_coords, nullptr);
+				if (rc)
+					break;
+				if (hipDeviceSynchronize() != hipSuccess)
+				{
+					set_error("merge tile search failed");
+					rc = 1;
+					break;
+				}
+				A->mem_footprint += 2.0 * (A->merge_num_tiles + 1) * 4;
+				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_MERGE_i%d_%s", A->merge_ipt, pf);
+				snprintf(A->kernel_name, sizeof(A->kernel_name), "merge_kernel");
+			}
+			break;
+		}
+		case SPMV_MI355X_SELL_C_SIGMA:
+		{
+			int C = o.sell_c ? o.sell_c : 64;
+			if (C != 16 && C != 32 && C != 64)
+			{
+				set_error("sell_c must be 16, 32 or 64 (got %d)", C);
+				rc = 1;
+				break;
+			}
+			long sigma = o.sell_sigma ? o.sell_sigma : 16384;
+			if (sigma < C || sigma % C)
+			{
+				set_error("sell_sigma (%ld) must be a positive multiple of sell_c (%d)", sigma, C);
+				rc = 1;
+				break;
+			}
+			A->sell_c = C;
+			A->sell_sigma = sigma;
+			rc = build_sell(A, rp, ci, va);
+			snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELL_%d_%ld_%s", C, sigma, pf);
+			snprintf(A->kernel_name, sizeof(A->kernel_name), "sell_kernel");
+			break;
+		}
+		case SPMV_MI355X_COO:
+		{
+			rc = upload_ints(rp, (size_t) lm + 1, &A->d_row_ptr) || upload_ints(ci, (size_t) lnnz, &A->d_col) ||
+			     upload_values(A, va, (size_t) lnnz, &A->d_val) || dev_alloc(&A->d_rowind, (size_t) lnnz);
+			if (rc)
+				break;
+			rc = launch_expand_rows(A->d_row_ptr, (int) lm, A->d_rowind, nullptr);
+			if (rc)
+				break;
+			if (hipDeviceSynchronize() != hipSuccess)
+			{
+				set_error("COO row expansion failed");
+				rc = 1;
+				break;
+			}
+			(void) hipFree(A->d_row_ptr);          // COO keeps (rowind, colind, val) only: mkl_coo.cpp:65
+			A->d_row_ptr = nullptr;
+			int per_wave = coo_wave_items(o.merge_items);
+			A->coo_k = per_wave / WAVE;
+			A->coo_num_waves = (int) ((lnnz + per_wave - 1) / per_wave);
+			rc = dev_alloc(&A->d_carry_row, (size_t) A->coo_num_waves) ||
+			     dev_alloc_bytes(&A->d_carry_val, (size_t) A->coo_num_waves * A->vbytes);
+			A->mem_footprint = (double) lnnz * (A->vbytes + 8);
+			snprintf(A->format_name, sizeof(A->format_name), "MI355X_COO_k%d_%s", A->coo_k, pf);
+			snprintf(A->kernel_name, sizeof(A->kernel_name), "coo_kernel");
+			break;
+		}
+	}
+	if (rc)
+	{
+		free_all(A);
+		delete A;
+		return 1;
+	}
+	*out = A;
+	return 0;
+}
+
+int
+spmv_mi355x_destroy(spmv_mi355x_matrix * A)
+{
+	if (!A)
+		return 0;
+	(void) hipSetDevice(A->device);
+	free_all(A);
+	delete A;
+	return 0;
+}
+
+const char * spmv_mi355x_format_name(const spmv_mi355x_matrix * A) { return A->format_name; }
+double spmv_mi355x_mem_footprint(const spmv_mi355x_matrix * A) { return A->mem_footprint; }
+double spmv_mi355x_csr_mem_footprint(const spmv_mi355x_matrix * A) { return A->csr_mem_footprint; }
+long spmv_mi355x_rows(const spmv_mi355x_matrix * A) { return A->m; }
+long spmv_mi355x_cols(const spmv_mi355x_matrix * A) { return A->n; }
+long spmv_mi355x_nnz(const spmv_mi355x_matrix * A) { return A->nnz; }
+
+int
+spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, int beta, void * hip_stream)
+{
+	hipStream_t st = (hipStream_t) hip_stream;
+	LaunchCfg cfg = A->cfg;
+	cfg.beta = beta ? 1 : 0;
+	long grid = 0;
+	int rc = 1;
+	switch (A->format)
+	{
+		case SPMV_MI355X_CSR_SCALAR:
+			rc = launch_csr_scalar(A->f32, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
+			break;
+		case SPMV_MI355X_CSR_VECTOR:
+			rc = launch_csr_vector(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
+			break;
+		case SPMV_MI355X_CSR_MERGE:
+			rc = launch_merge(A->f32, A->merge_ipt, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, (int) A->nnz,
+					A->merge_num_tiles, A->d_coords, A->d_carry_row, A->d_carry_val, cfg, st, &grid);
+			break;
+		case SPMV_MI355X_SELL_C_SIGMA:
+			rc = launch_sell(A->f32, A->sell_c, A->d_slice_ptr, A->d_col, A->d_val, A->d_row_of_sorted, x, y, (int) A->m,
+					(int) A->sell_slices, cfg, st, &grid);
+			break;
+		case SPMV_MI355X_COO:
+			rc = launch_coo(A->f32, A->coo_k, A->d_rowind, A->d_col, A->d_val, x, y, (int) A->m, A->nnz, A->coo_num_waves,
+					A->d_carry_row, A->d_carry_val, cfg, st, &grid);
+			break;
+		default:
+			set_error("bad handle");
+	}
+	A->last_grid = grid;
+	return rc;
+}
+
+int
+spmv_mi355x_time_device(spmv_mi355x_matrix * A, const void * x, void * y, int iters, void * hip_stream, double * ms_out)
+{
+	hipStream_t st = (hipStream_t) hip_stream;
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipEventRecord(e0, st));
+	for (int i = 0; i < iters; i++)
+		if (spmv_mi355x_spmv_device_async(A, x, y, 0, hip_stream))
+			return 1;
+	HIP_TRY(hipEventRecord(e1, st));
+	HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void) hipEventDestroy(e0);
+	(void) hipEventDestroy(e1);
+	*ms_out = iters > 0 ? (double) ms / iters : 0;
+	return 0;
+}
+
+int
+spmv_mi355x_kernel_info(const spmv_mi355x_matrix * A, char * name_out, long name_n, long * grid_out, int * block_out)
+{
+	if (name_out && name_n > 0)
+		snprintf(name_out, name_n, "%s", A->kernel_name);
+	if (grid_out)
+		*grid_out = A->last_grid;
+	if (block_out)
+		*block_out = 256;
+	return 0;
+}
+
+static int
+ensure_xy(spmv_mi355x_matrix * A)
+{
+	HIP_TRY(hipSetDevice(A->device));
+	if (!A->stream)
+		HIP_TRY(hipStreamCreate(&A->stream));
+	if (!A->d_x && dev_alloc_bytes(&A->d_x, (size_t) std::max<long>(A->n, 1) * A->vbytes))
+		return 1;
+	if (!A->d_y && dev_alloc_bytes(&A->d_y, (size_t) (A->m + 64) * A->vbytes))
+		return 1;
+	return 0;
+}
+
+void * spmv_mi355x_x_device(spmv_mi355x_matrix * A) { return ensure_xy(A) ? nullptr : A->d_x; }
+void * spmv_mi355x_y_device(spmv_mi355x_matrix * A) { return ensure_xy(A) ? nullptr : A->d_y; }
+
+int
+spmv_mi355x_set_always_copy(spmv_mi355x_matrix * A, int on)
+{
+	A->always_copy = on != 0;
+	return 0;
+}
+
+int
+spmv_mi355x_upload_x(spmv_mi355x_matrix * A, const void * x_host)
+{
+	if (ensure_xy(A))
+		return 1;
+	HIP_TRY(hipMemcpyAsync(A->d_x, x_host, (size_t) A->n * A->vbytes, hipMemcpyHostToDevice, A->stream));
+	HIP_TRY(hipStreamSynchronize(A->stream));
+	A->cached_x_host = x_host;
+	return 0;
+}
+
+int
+spmv_mi355x_download_y(spmv_mi355x_matrix * A, void * y_host)
+{
+	if (ensure_xy(A))
+		return 1;
+	HIP_TRY(hipMemcpyAsync(y_host, A->d_y, (size_t) A->m * A->vbytes, hipMemcpyDeviceToHost, A->stream));
+	HIP_TRY(hipStreamSynchronize(A->stream));
+	A->y_downloaded = true;
+	return 0;
+}
+
+// Matrix_Format::spmv with the reference GPU backends' caching convention (csr_rocm_vector.cpp:224-257).
+int
+spmv_mi355x_spmv(spmv_mi355x_matrix * A, const void * x_host, void * y_host)
+{
+	if (ensure_xy(A))
+		return 1;
+	if (A->always_copy || A->cached_x_host != x_host)
+		if (spmv_mi355x_upload_x(A, x_host))
+			return 1;
+	if (spmv_mi355x_spmv_device_async(A, A->d_x, A->d_y, 0, A->stream))
+		return 1;
+	HIP_TRY(hipStreamSynchronize(A->stream));
+	if (A->always_copy || !A->y_downloaded)
+		if (spmv_mi355x_download_y(A, y_host))
+			return 1;
+	return 0;
+}
+
+int
+spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma_out, long * num_slices_out,
+		long * nnz_ext_out, int64_t ** slice_ptr_out, int32_t ** col_out, double ** val_out, int32_t ** row_of_sorted_out)
+{
+	if (A->format != SPMV_MI355X_SELL_C_SIGMA)
+	{
+		set_error("not a SELL handle");
+		return 1;
+	}
+	HIP_TRY(hipSetDevice(A->device));
+	if (C_out) *C_out = A->sell_c;
+	if (sigma_out) *sigma_out = A->sell_sigma;
+	if (num_slices_out) *num_slices_out = A->sell_slices;
+	if (nnz_ext_out) *nnz_ext_out = A->sell_nnz_ext;
+	if (slice_ptr_out)
+	{
+		*slice_ptr_out = (int64_t *) malloc(((size_t) A->sell_slices + 1) * sizeof(int64_t));
+		HIP_TRY(hipMemcpy(*slice_ptr_out, A->d_slice_ptr, ((size_t) A->sell_slices + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+	}
+	size_t ne = (size_t) std::max<long>(A->sell_nnz_ext, 1);
+	if (col_out)
+	{
+		*col_out = (int32_t *) malloc(ne * sizeof(int32_t));
+		HIP_TRY(hipMemcpy(*col_out, A->d_col, (size_t) A->sell_nnz_ext * sizeof(int32_t), hipMemcpyDeviceToHost));
+	}
+	if (val_out)
+	{
+		*val_out = (double *) malloc(ne * sizeof(double));
+		if (!A->f32)
+			HIP_TRY(hipMemcpy(*val_out, A->d_val, (size_t) A->sell_nnz_ext * sizeof(double), hipMemcpyDeviceToHost));
+		else
+		{
+			std::vector<float> tmp(ne);
+			HIP_TRY(hipMemcpy(tmp.data(), A->d_val, (size_t) A->sell_nnz_ext * sizeof(float), hipMemcpyDeviceToHost));
+			for (size_t i = 0; i < (size_t) A->sell_nnz_ext; i++)
+				(*val_out)[i] = tmp[i];
+		}
+	}
+	if (row_of_sorted_out)
+	{
+		*row_of_sorted_out = (int32_t *) malloc((size_t) std::max<long>(A->m, 1) * sizeof(int32_t));
+		HIP_TRY(hipMemcpy(*row_of_sorted_out, A->d_row_of_sorted, (size_t) A->m * sizeof(int32_t), hipMemcpyDeviceToHost));
+	}
+	return 0;
+}
+
+int
+spmv_mi355x_merge_tiles(const spmv_mi355x_matrix * A, long * num_tiles_out, long * tile_items_out, int32_t ** coords_out)
+{
+	if (A->format != SPMV_MI355X_CSR_MERGE)
+	{
+		set_error("not a merge handle");
+		return 1;
+	}
+	HIP_TRY(hipSetDevice(A->device));
+	if (num_tiles_out) *num_tiles_out = A->merge_num_tiles;
+	if (tile_items_out) *tile_items_out = A->merge_tile;
+	if (coords_out)
+	{
+		size_t cnt = 2 * ((size_t) A->merge_num_tiles + 1);
+		*coords_out = (int32_t *) malloc(cnt * sizeof(int32_t));
+		HIP_TRY(hipMemcpy(*coords_out, A->d_coords, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+	}
+	return 0;
+}
+
+void
+spmv_mi355x_free(void * p)
+{
+	free(p);
+}
+
+}  // extern "C"

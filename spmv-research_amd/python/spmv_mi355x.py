@@ -1,0 +1,200 @@
+"""ctypes binding of the C ABI in include/spmv_mi355x.h (libspmv_mi355x.so, hand-written HIP for gfx950).
+
+This is test/bench plumbing above the C ABI: the same entry points the reference harness would bind through
+host/spmv_kernel_mi355x.cpp. There is no fallback: if the shared object is missing or no GPU is usable, the
+calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libspmv_mi355x.so")
+
+CSR_SCALAR, CSR_VECTOR, CSR_MERGE, SELL_C_SIGMA, COO = range(5)
+FORMATS = {"csr_scalar": CSR_SCALAR, "csr_vector": CSR_VECTOR, "csr_merge": CSR_MERGE,
+           "sell_c_sigma": SELL_C_SIGMA, "coo": COO}
+F64, F32 = 0, 1
+
+
+class Opts(C.Structure):
+    _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("lanes_per_row", C.c_int),
+                ("block_threads", C.c_int), ("sell_c", C.c_int), ("sell_sigma", C.c_int),
+                ("merge_items", C.c_int), ("xcd_remap", C.c_int), ("nontemporal", C.c_int),
+                ("reserved0", C.c_int),
+                ("row_begin", C.c_long), ("row_end", C.c_long), ("col_begin", C.c_long), ("col_end", C.c_long),
+                ("col_filter_mode", C.c_int), ("reserved1", C.c_int)]
+
+
+# every symbol declared in include/spmv_mi355x.h (checked by tests/test_abi.py)
+SYMBOLS = [
+    "spmv_mi355x_last_error", "spmv_mi355x_device_count", "spmv_mi355x_device_info", "spmv_mi355x_create",
+    "spmv_mi355x_destroy", "spmv_mi355x_format_name", "spmv_mi355x_mem_footprint", "spmv_mi355x_csr_mem_footprint",
+    "spmv_mi355x_rows", "spmv_mi355x_cols", "spmv_mi355x_nnz", "spmv_mi355x_spmv", "spmv_mi355x_set_always_copy",
+    "spmv_mi355x_upload_x", "spmv_mi355x_download_y", "spmv_mi355x_spmv_device_async", "spmv_mi355x_time_device",
+    "spmv_mi355x_kernel_info", "spmv_mi355x_x_device", "spmv_mi355x_y_device", "spmv_mi355x_sell_layout",
+    "spmv_mi355x_merge_tiles", "spmv_mi355x_free",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C spmv-research_amd` "
+                               "(__graft_entry__.build()). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.spmv_mi355x_last_error.restype = C.c_char_p
+        L.spmv_mi355x_format_name.restype = C.c_char_p
+        L.spmv_mi355x_mem_footprint.restype = C.c_double
+        L.spmv_mi355x_csr_mem_footprint.restype = C.c_double
+        for f in ("spmv_mi355x_rows", "spmv_mi355x_cols", "spmv_mi355x_nnz"):
+            getattr(L, f).restype = C.c_long
+        L.spmv_mi355x_x_device.restype = C.c_void_p
+        L.spmv_mi355x_y_device.restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+class SpmvError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise SpmvError(lib().spmv_mi355x_last_error().decode())
+
+
+def device_count():
+    c = C.c_int()
+    _check(lib().spmv_mi355x_device_count(C.byref(c)))
+    return c.value
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    cu = C.c_int()
+    mem = C.c_long()
+    _check(lib().spmv_mi355x_device_info(device, name, C.c_long(256), C.byref(cu), C.byref(mem)))
+    return dict(name=name.value.decode(), compute_units=cu.value, hbm_bytes=mem.value)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Matrix:
+    """One converted matrix on one GPU = the reference's `struct Matrix_Format` instance."""
+
+    def __init__(self, row_ptr, col_idx, values, m, n, fmt="csr_vector", dtype=np.float64, **opts):
+        row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+        col_idx = np.ascontiguousarray(col_idx, np.int32)
+        values = np.ascontiguousarray(values, np.float64)
+        self.dtype = np.dtype(dtype)
+        o = Opts()
+        o.struct_size = C.sizeof(Opts)
+        o.device = -1
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(o, k, v)
+        self.h = C.c_void_p()
+        fmt_id = FORMATS[fmt] if isinstance(fmt, str) else fmt
+        _check(lib().spmv_mi355x_create(C.byref(self.h), fmt_id, F64 if self.dtype == np.float64 else F32,
+                                        C.c_long(m), C.c_long(n), C.c_long(len(col_idx)),
+                                        _p(row_ptr), _p(col_idx), _p(values), C.byref(o)))
+        L = lib()
+        self.m = L.spmv_mi355x_rows(self.h)
+        self.n = L.spmv_mi355x_cols(self.h)
+        self.nnz = L.spmv_mi355x_nnz(self.h)
+        self.format_name = L.spmv_mi355x_format_name(self.h).decode()
+        self.mem_footprint = L.spmv_mi355x_mem_footprint(self.h)
+        self.csr_mem_footprint = L.spmv_mi355x_csr_mem_footprint(self.h)
+
+    # Matrix_Format::spmv(x, y) on host buffers; y gets the driver's +64 slack and 1.0 canary (bench_spmv.cpp:606-609)
+    def spmv(self, x, always_copy=True):
+        x = np.ascontiguousarray(x, self.dtype)
+        assert x.shape[0] == self.n
+        y = np.ones(self.m + 64, self.dtype)
+        lib().spmv_mi355x_set_always_copy(self.h, 1 if always_copy else 0)
+        _check(lib().spmv_mi355x_spmv(self.h, _p(x), _p(y)))
+        return y[:self.m].copy()
+
+    def spmv_raw(self, x, y):
+        """Exact reference call shape: caller-owned buffers, reference caching semantics."""
+        _check(lib().spmv_mi355x_spmv(self.h, _p(x), _p(y)))
+
+    def set_always_copy(self, on):
+        lib().spmv_mi355x_set_always_copy(self.h, 1 if on else 0)
+
+    def spmv_device(self, x_ptr, y_ptr, beta=0, stream=0):
+        _check(lib().spmv_mi355x_spmv_device_async(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_int(beta),
+                                                   C.c_void_p(stream)))
+
+    def time_device(self, x_ptr, y_ptr, iters, stream=0):
+        ms = C.c_double()
+        _check(lib().spmv_mi355x_time_device(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_int(iters),
+                                             C.c_void_p(stream), C.byref(ms)))
+        return ms.value
+
+    def kernel_info(self):
+        name = C.create_string_buffer(128)
+        grid = C.c_long()
+        block = C.c_int()
+        _check(lib().spmv_mi355x_kernel_info(self.h, name, C.c_long(128), C.byref(grid), C.byref(block)))
+        return dict(name=name.value.decode(), grid=grid.value, block=block.value)
+
+    def x_device(self):
+        return lib().spmv_mi355x_x_device(self.h)
+
+    def y_device(self):
+        return lib().spmv_mi355x_y_device(self.h)
+
+    def upload_x(self, x):
+        x = np.ascontiguousarray(x, self.dtype)
+        _check(lib().spmv_mi355x_upload_x(self.h, _p(x)))
+
+    def download_y(self):
+        y = np.zeros(self.m, self.dtype)
+        _check(lib().spmv_mi355x_download_y(self.h, _p(y)))
+        return y
+
+    def sell_layout(self):
+        Cc, sig, ns, ne = C.c_long(), C.c_long(), C.c_long(), C.c_long()
+        sp = C.POINTER(C.c_int64)()
+        col = C.POINTER(C.c_int32)()
+        val = C.POINTER(C.c_double)()
+        ros = C.POINTER(C.c_int32)()
+        _check(lib().spmv_mi355x_sell_layout(self.h, C.byref(Cc), C.byref(sig), C.byref(ns), C.byref(ne),
+                                             C.byref(sp), C.byref(col), C.byref(val), C.byref(ros)))
+        out = dict(C=Cc.value, sigma=sig.value, num_slices=ns.value, nnz_ext=ne.value,
+                   slice_ptr=np.ctypeslib.as_array(sp, shape=(ns.value + 1,)).copy(),
+                   col=np.ctypeslib.as_array(col, shape=(max(ne.value, 1),))[:ne.value].copy(),
+                   val=np.ctypeslib.as_array(val, shape=(max(ne.value, 1),))[:ne.value].copy(),
+                   row_of_sorted=np.ctypeslib.as_array(ros, shape=(max(self.m, 1),))[:self.m].copy())
+        for p in (sp, col, val, ros):
+            lib().spmv_mi355x_free(p)
+        return out
+
+    def merge_tiles(self):
+        nt, ti = C.c_long(), C.c_long()
+        co = C.POINTER(C.c_int32)()
+        _check(lib().spmv_mi355x_merge_tiles(self.h, C.byref(nt), C.byref(ti), C.byref(co)))
+        coords = np.ctypeslib.as_array(co, shape=(2 * (nt.value + 1),)).copy().reshape(-1, 2)
+        lib().spmv_mi355x_free(co)
+        return dict(num_tiles=nt.value, tile_items=ti.value, coords=coords)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().spmv_mi355x_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
