@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""bench.py — SpMV throughput of the MI355X engine on the BASELINE.json configurations.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU (RCCL). Rank 0 prints ONE JSON line.
+
+A "step" is one y = A*x over the whole matrix with the matrix, x and y already resident in HBM:
+  N = 1 : one launch of the selected HIP kernel (through the C ABI, include/spmv_mi355x.h);
+  N > 1 : row-block partition (nnz-balanced, the reference's per-thread partitioner applied to GPUs);
+          every step = RCCL allgather of x over xGMI (forced every step, as in a solver where x changes) overlapped
+          with the local-column part of the block, then the remote-column part accumulated into y. Total work is
+          fixed as N grows -> "scaling": "strong".
+
+Default workload: 'nlpkkt240' (config 5 of BASELINE.json: 28.0 M rows, ~770 M non-zeros, fp64) — the largest
+single-GPU configuration, the one the multi-GPU target is quoted on, and far larger than the 256 MiB Infinity Cache,
+so the algorithmic GB/s below is real HBM traffic. The matrices are synthetic twins (no SuiteSparse file exists in
+the reference tree and there is no network): see spmv-research_amd/host/synthetic.cpp and DESIGN.md.
+
+metric/value: GFLOP/s = 2*nnz / t (true stored nnz; the reference's printed GFLOPS is ~2x inflated for general
+matrices). roofline.achieved: algorithmic bytes B_alg = nnz*(sizeof(V)+4) + (m+1)*4 + (n+m)*sizeof(V)
+per launch / mean kernel time from HIP events recorded on the launch stream over the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "spmv-research_amd", "python"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+DEFAULT_FORMAT = {"nlpkkt240": "csr_vector", "cant": "csr_vector", "pwtk": "sell_c_sigma",
+                  "scircuit": "csr_vector", "soc-LiveJournal1": "csr_merge"}
+DEFAULT_DTYPE = {"pwtk": "f32"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="nlpkkt240",
+                    help="cant | scircuit | pwtk | soc-LiveJournal1 | nlpkkt240 (synthetic twins)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (tests only; invalid as a result)")
+    ap.add_argument("--format", default=None, help="csr_scalar|csr_vector|csr_merge|sell_c_sigma|coo")
+    ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
+    ap.add_argument("--lanes-per-row", type=int, default=0)
+    ap.add_argument("--sell-c", type=int, default=0)
+    ap.add_argument("--sell-sigma", type=int, default=0)
+    ap.add_argument("--merge-items", type=int, default=0)
+    ap.add_argument("--nontemporal", type=int, default=0)
+    ap.add_argument("--xcd-remap", type=int, default=0)
+    ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap allgather(x) with the local-column part")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(m, n, nnz, vbytes):
+    return nnz * (vbytes + 4) + (m + 1) * 4 + (n + m) * vbytes
+
+
+def kkt_edge(scale):
+    return max(4, int(round(240 * scale ** (1.0 / 3.0))))
+
+
+def load_traffic(workload, fmt, dtype):
+    """HBM bytes per launch from the rocprofv3 PMC passes (tools/collect_traffic.py -> profiles/traffic_*.json)."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(pdir):
+        return None
+    for f in sorted(os.listdir(pdir)):
+        if f.startswith("traffic_") and f.endswith(".json"):
+            try:
+                with open(os.path.join(pdir, f)) as fh:
+                    for rec in json.load(fh).get("records", []):
+                        if rec.get("workload") == workload and rec.get("format") == fmt and rec.get("dtype") == dtype \
+                                and rec.get("scale", 1.0) == 1.0:
+                            best = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+    return best
+
+
+def main():
+    args = parse()
+    import torch
+    import spmv_host as H
+    import spmv_mi355x as E
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank))
+
+    workload = args.workload
+    fmt = args.format or DEFAULT_FORMAT.get(workload, "csr_vector")
+    dts = args.dtype or DEFAULT_DTYPE.get(workload, "f64")
+    np_dtype = np.float64 if dts == "f64" else np.float32
+    t_dtype = torch.float64 if dts == "f64" else torch.float32
+    vbytes = 8 if dts == "f64" else 4
+    opts = {}
+    for k, v in (("lanes_per_row", args.lanes_per_row), ("sell_c", args.sell_c), ("sell_sigma", args.sell_sigma),
+                 ("merge_items", args.merge_items), ("nontemporal", args.nontemporal), ("xcd_remap", args.xcd_remap)):
+        if v:
+            opts[k] = v
+
+    # ------------------------------------------------------------------ matrix (synthetic twin), row partition
+    t_gen = time.time()
+    if workload == "nlpkkt240":
+        N = kkt_edge(args.scale)
+        if world == 1:
+            A = H.gen_kkt(N)
+            m = n = A["m"]
+            nnz_total = A["nnz"]
+            row_ptr_g = A["row_ptr"]
+            blk = A
+            r0, r1 = 0, m
+        else:
+            row_ptr_g = H.gen_kkt_row_ptr(N)
+            m = n = len(row_ptr_g) - 1
+            nnz_total = int(row_ptr_g[m])
+    else:
+        A = H.gen_named(workload, args.scale)
+        m, n, nnz_total, row_ptr_g = A["m"], A["n"], A["nnz"], A["row_ptr"]
+        blk = A
+        r0, r1 = 0, m
+    offsets = None
+    if world > 1:
+        # nnz-balanced contiguous row blocks: lib/parallel_util.h:156-184 applied with W = number of GPUs
+        offsets = np.zeros(world + 1, np.int64)
+        for p in range(world):
+            s, e = H.partition_prefix_sums(world, p, row_ptr_g, m, nnz_total)
+            offsets[p], offsets[p + 1] = s, e
+        r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
+        if workload == "nlpkkt240":
+            blk = H.gen_kkt_block(kkt_edge(args.scale), r0, r1)
+        else:
+            s, e = int(row_ptr_g[r0]), int(row_ptr_g[r1])
+            blk = dict(m=r1 - r0, n=n, nnz=e - s, row_ptr=(row_ptr_g[r0:r1 + 1] - s).astype(np.int32),
+                       col_idx=A["col_idx"][s:e].copy(), values=A["values"][s:e].copy())
+            del A
+        assert m == n, "row-partitioned allgather(x) assumes a square matrix (x slices follow the row blocks)"
+        padded = int((np.diff(offsets).max() + 63) // 64 * 64)
+        H.remap_columns(blk["col_idx"], offsets, padded)      # x lives as `world` slices padded to a common length
+        n_x = padded * world
+    else:
+        padded = n
+        n_x = n
+    t_gen = time.time() - t_gen
+    lm, lnnz = blk["m"], blk["nnz"]
+
+    # ------------------------------------------------------------------ device state
+    t_conv = time.time()
+    if world == 1:
+        mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype, **opts)]
+    elif args.overlap:
+        c0, c1 = rank * padded, rank * padded + (r1 - r0)
+        mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype,
+                         col_begin=c0, col_end=c1, col_filter_mode=1, **opts),
+                E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype,
+                         col_begin=c0, col_end=c1, col_filter_mode=2, **opts)]
+    else:
+        mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype, **opts)]
+    t_conv = time.time() - t_conv
+
+    rng = np.random.default_rng(14)
+    x_host = rng.uniform(-1.0, 1.0, n).astype(np_dtype)       # global x (same on every rank)
+    x_full = torch.zeros(n_x, dtype=t_dtype, device="cuda")
+    if world == 1:
+        x_full.copy_(torch.from_numpy(x_host))
+        x_loc = x_full
+    else:
+        x_loc = x_full[rank * padded:(rank + 1) * padded]         # in-place allgather: own slice lives inside x_full
+        x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
+    y = torch.full((lm + 64,), 1.0, dtype=t_dtype, device="cuda")  # driver canary (bench_spmv.cpp:606-609)
+    compute = torch.cuda.current_stream()
+    sp = compute.cuda_stream
+
+    def step():
+        if world == 1:
+            mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
+        elif args.overlap:
+            work = dist.all_gather_into_tensor(x_full, x_loc, async_op=True)
+            mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)      # local columns: only the own slice of x
+            work.wait()
+            mats[1].spmv_device(x_full.data_ptr(), y.data_ptr(), 1, sp)      # remote columns, y += ...
+        else:
+            dist.all_gather_into_tensor(x_full, x_loc)
+            mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    # ------------------------------------------------------------------ timed region
+    K = args.steps
+    kernel_ms = None
+    if world == 1:
+        t0 = time.perf_counter()
+        kernel_ms = mats[0].time_device(x_full.data_ptr(), y.data_ptr(), K, sp)   # HIP events on the launch stream
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    else:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        t0 = time.perf_counter()
+        for i in range(K):
+            ev[i][0].record(compute)
+            step()
+            ev[i][1].record(compute)
+        barrier()
+        t1 = time.perf_counter()
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))              # per step on the compute stream
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / K * 1e3
+
+    # ------------------------------------------------------------------ sanity: sampled rows against a host dot product
+    yh = y[:lm].cpu().numpy().astype(np.float64)
+    samp = np.unique(np.random.default_rng(1).integers(0, max(lm, 1), 2000)) if lm > 0 else np.array([], np.int64)
+    xg = x_host.astype(np.float64)
+    if world > 1:
+        own = np.repeat(np.arange(world), np.diff(offsets))
+    max_rel = 0.0
+    rp, ci, va = blk["row_ptr"], blk["col_idx"], blk["values"]
+    for i in samp:
+        cols = ci[rp[i]:rp[i + 1]].astype(np.int64)
+        if world > 1:
+            p = cols // padded
+            cols = offsets[p] + (cols - p * padded)
+        vals = va[rp[i]:rp[i + 1]].astype(np_dtype).astype(np.float64)
+        ref = float(np.dot(vals, xg[cols]))
+        den = float(np.dot(np.abs(vals), np.abs(xg[cols]))) or 1.0
+        max_rel = max(max_rel, abs(ref - yh[i]) / den)
+    tol = 1e-12 if dts == "f64" else 1e-5
+    if not (max_rel <= tol) or not np.all(yh[:lm] == yh[:lm]):
+        raise SystemExit(f"bench sanity check failed: sampled rows differ from the host dot products (max {max_rel})")
+
+    # ------------------------------------------------------------------ report
+    gflops = 2.0 * nnz_total / (ms_per_step * 1e-3) / 1e9
+    B_alg = algorithmic_bytes(m, n, nnz_total, vbytes)
+    B_alg_local = algorithmic_bytes(lm, n_x if world == 1 else n, lnnz, vbytes)
+    ach = B_alg_local / (kernel_ms * 1e-3) / 1e9
+    ki = mats[0].kernel_info()
+    result = {
+        "metric": "GFLOP/s (2*nnz/t, fp64 SpMV y=A*x); achieved HBM GB/s and % of peak in 'roofline'",
+        "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
+        "scaling": "strong",            # total work (one SpMV of the whole matrix) is fixed as N grows
+        "vs_baseline": None, "dtype": dts, "data": "synthetic",
+        "config": {"workload": f"{workload} (synthetic twin)" + ("" if args.scale == 1.0 else f" scale={args.scale}"),
+                   "format": mats[0].format_name, "rows": int(m), "cols": int(n), "nnz": int(nnz_total),
+                   "parallelism": "single GPU" if world == 1 else
+                   f"row-partitioned x{world}, RCCL allgather(x) {'overlapped with local columns' if args.overlap else 'then SpMV'}"},
+        "hbm_gbps_algorithmic": round(B_alg / (ms_per_step * 1e-3) / 1e9, 2),
+        "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 2),
+        "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(ach / HBM_PEAK_GBPS, 4),
+                     "traffic": load_traffic(workload, fmt, dts) if world == 1 and args.scale == 1.0 else None,
+                     "kernel": ki["name"], "kernel_ms": round(kernel_ms, 6),
+                     "algorithmic_bytes_per_launch": int(B_alg_local)},
+        "check_max_err_over_abs_row": max_rel,
+        "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t_conv, 2)},
+    }
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1): the oracle = port
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc                                  # checker only: timed beside the GPU, never shipped
+        # the GPU box shows every host CPU but one GPU's share is 16 cores (oversubscribing 256 threads is 10x slower)
+        cores = int(os.environ.get("SPMV_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+        max_nnz = 64_000_000
+        if lnnz > max_nnz:
+            rs = int(np.searchsorted(rp, max_nnz))
+            sample = f"first {rs} rows ({int(rp[rs])} nnz) of {workload}"
+        else:
+            rs = lm
+            sample = f"whole {workload} twin ({lnnz} nnz)"
+        snnz = int(rp[rs])
+        tb = orc.time_csr_spmv(rp[:rs + 1], ci[:snnz], va[:snnz], x_host.astype(np.float64), cores,
+                               min_loops=5, min_runtime=args.cpu_baseline_seconds)
+        result["cpu_baseline"] = {"value": round(2.0 * snnz / tb["median"] / 1e9, 3), "unit": "GFLOP/s",
+                                  "cores": cores, "kind": "port", "sample": sample,
+                                  "median_s": tb["median"], "loops": tb["loops"],
+                                  "gbps": round(algorithmic_bytes(rs, n, snnz, 8) / tb["median"] / 1e9, 2)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

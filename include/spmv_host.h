@@ -79,6 +79,14 @@ int  spmv_host_gen_named(const char * name, double scale, spmv_host_csr * out);
  * the size of nlpkkt240). */
 int  spmv_host_gen_kkt(long N, unsigned long seed, spmv_host_csr * out);
 
+/* Row-partitioned generation (each rank of a multi-GPU run builds only its block): the global row_ptr alone
+ * (row_ptr may be NULL to query m), and rows [row_begin,row_end) as a local CSR with global column indices. */
+int  spmv_host_gen_kkt_row_ptr(long N, int32_t * row_ptr /* [m+1] or NULL */, long * m_out, long * nnz_out);
+int  spmv_host_gen_kkt_block(long N, unsigned long seed, long row_begin, long row_end, spmv_host_csr * out);
+/* x kept as `parts` slices padded to `padded` entries (one equal-sized allgather): column c of part p becomes
+ * p*padded + (c - offsets[p]); offsets has parts+1 entries. In place. */
+int  spmv_host_remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, long padded);
+
 /* Structural features the reference uses to describe a matrix (lib/storage_formats/csr_util/csr_util_gen.c:437-447,
  * 596-695,961): out[0..6] = avg nnz/row, std nnz/row, avg bandwidth scaled by n, skew = (max-avg)/avg,
  * avg_num_neighbours (window 1), cross_row_similarity (window 1), max nnz/row. */

@@ -186,7 +186,7 @@ orc_mtx_read(const char * filename, int num_threads, orc_coo_t * out, char * err
 			{
 				R[j] = C[i];
 				C[j] = R[i];
-				V[j] = skew ? -V[i] : V[i];
+				V[j] = (skew && !is_pat) ? -V[i] : V[i];   /* pattern values are filled with 1.0 after the expansion */
 				if (is_cplx)
 					Vim[j] = skew ? Vim[i] : -Vim[i];   /* -conj(z) / conj(z) */
 				j++;

@@ -1,0 +1,47 @@
+// Internal header of libspmv_host.so (host side of the MI355X SpMV engine; see include/spmv_host.h).
+#pragma once
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/spmv_host.h"
+
+namespace spmv_host {
+
+void set_error(const char * fmt, ...);
+
+// lib/parallel_util.h:47-91 (increment +1) and :156-184 of the reference
+void partition_iterations(long num_workers, long worker_pos, long start, long end, long * s, long * e);
+void partition_prefix_sums(long num_workers, long worker_pos, const int32_t * sums, long N, long total_sum, long * s, long * e);
+
+int mtx_read(const char * filename, spmv_host_coo * out);
+int coo_to_csr(const int32_t * R, const int32_t * C, const double * V, long m, long n, long nnz,
+		int32_t * row_ptr, int32_t * col_idx, double * values);
+
+int gen_twin(long nr_rows, long nr_cols, double avg, double std, double bw_scaled, double skew, double neigh,
+		double crs, unsigned long seed, int pattern, spmv_host_csr * out);
+int gen_kkt(long N, unsigned long seed, spmv_host_csr * out);
+int gen_kkt_row_ptr(long N, int32_t * row_ptr, long * m_out, long * nnz_out);
+int gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out);
+int remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, long padded);
+int csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out7);
+
+// counter-based generator: independent stream per (seed, row) so the generators are parallel AND deterministic
+struct Rng {
+	uint64_t s;
+	explicit Rng(uint64_t seed, uint64_t stream) : s(seed * 0x9E3779B97F4A7C15ull + stream * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull) { next(); next(); }
+	inline uint64_t next()
+	{
+		uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		return z ^ (z >> 31);
+	}
+	inline double uniform() { return (double) (next() >> 11) * (1.0 / 9007199254740992.0); }      // [0,1)
+	inline double uniform(double a, double b) { return a + (b - a) * uniform(); }
+	inline long below(long n) { return (long) (uniform() * (double) n); }
+	double normal();
+};
+
+}  // namespace spmv_host

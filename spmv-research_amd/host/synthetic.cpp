@@ -1,0 +1,438 @@
+// Synthetic stand-ins for the SuiteSparse matrices named in BASELINE.json. No .mtx file ships with the reference and
+// there is no network, and the reference's own generator (artificial-matrix-generator/) is an un-vendored, empty
+// submodule, so these generators are OURS. They consume the reference's feature vector (argument order of
+// benchmark_code/BENCH/src/bench.cpp:569-579; the strings for cant / scircuit / pwtk / soc-LiveJournal1 are at
+// benchmark_code/BENCH/config.sh:402,413,430,449; feature definitions lib/storage_formats/csr_util/csr_util_gen.c:
+// 437-447,596-695,961) and produce sorted-column CSR directly, in parallel, deterministically per (seed, row).
+//
+// nlpkkt240 has no twin string: gen_kkt() builds a symmetric KKT-shaped matrix [H A^T; A 0] over an N^3 grid
+// (m = 2N^3 + 6N^2 = 27,993,600 and ~770 M non-zeros for N = 240; 27-point H, two 7-point stencils per constraint row).
+
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <vector>
+#include <omp.h>
+
+#include "host.hpp"
+
+namespace spmv_host {
+
+double
+Rng::normal()
+{
+	// Box-Muller, one value per call
+	double u1 = uniform(), u2 = uniform();
+	if (u1 < 1e-300)
+		u1 = 1e-300;
+	return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+static int
+alloc_csr(spmv_host_csr * out, long m, long n, long nnz)
+{
+	out->m = m;
+	out->n = n;
+	out->nnz = nnz;
+	out->row_ptr = (int32_t *) malloc(((size_t) m + 1) * sizeof(int32_t));
+	out->col_idx = (int32_t *) malloc((size_t) std::max<long>(nnz, 1) * sizeof(int32_t));
+	out->values = (double *) malloc((size_t) std::max<long>(nnz, 1) * sizeof(double));
+	if (!out->row_ptr || !out->col_idx || !out->values)
+	{
+		set_error("out of memory for a %ld x %ld matrix with %ld non-zeros", m, n, nnz);
+		return 1;
+	}
+	return 0;
+}
+
+// row length model: Normal(avg,std) when the spread is moderate, log-normal with the same mean/std when std > avg/2
+// (power-law-ish matrices such as soc-LiveJournal1: avg 14.2, std 36), clipped to [0,n]; rows on a geometric ladder
+// below avg*(1+skew) reproduce the `skew` feature (a few very long rows).
+static long
+row_length(Rng & g, double avg, double std, long n)
+{
+	double v;
+	if (std <= 0.5 * avg)
+		v = avg + std * g.normal();
+	else
+	{
+		double s2 = log(1.0 + (std / avg) * (std / avg));
+		v = exp(log(avg) - 0.5 * s2 + sqrt(s2) * g.normal());
+	}
+	long L = (long) floor(v + 0.5);
+	return std::min(std::max(L, 0L), n);
+}
+
+static void
+fill_row(Rng & g, long i, long m, long n, long L, double bw_scaled, double p_neigh, double crs,
+		const int32_t * prev, long prev_len, std::vector<int32_t> & cols)
+{
+	cols.clear();
+	if (L <= 0)
+		return;
+	// window of total span bw_scaled*n around the scaled diagonal
+	double span = std::max(bw_scaled * (double) n, (double) L * 1.25);
+	span = std::min(span, (double) n);
+	double centre = (m > 1) ? (double) i * (double) (n - 1) / (double) (m - 1) : 0;
+	long lo = (long) (centre - 0.5 * span), hi = lo + (long) span;
+	if (lo < 0) { hi -= lo; lo = 0; }
+	if (hi > n) { lo -= (hi - n); hi = n; }
+	if (lo < 0) lo = 0;
+	const long width = std::max(hi - lo, 1L);
+	long attempts = 0;
+	int32_t last = -1;
+	while ((long) cols.size() < L && attempts < 8 * L + 64)
+	{
+		attempts++;
+		int32_t c;
+		double u = g.uniform();
+		if (u < crs && prev_len > 0)
+		{
+			c = prev[g.below(prev_len)];                 // reuse a column of the previous row (cross-row similarity)
+			if (g.uniform() < 0.25)
+				c += (g.uniform() < 0.5) ? -1 : 1;
+		}
+		else if (last >= 0 && g.uniform() < p_neigh)
+			c = last + 1;                                // extend a run (same-row neighbours)
+		else
+			c = (int32_t) (lo + g.below(width));
+		if (c < 0 || c >= n)
+			continue;
+		cols.push_back(c);
+		last = c;
+		if ((long) cols.size() == L || (attempts & 63) == 0)
+		{
+			std::sort(cols.begin(), cols.end());
+			cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+		}
+	}
+	std::sort(cols.begin(), cols.end());
+	cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+	// top up deterministically if rejection sampling fell short (dense windows)
+	for (long c = lo; (long) cols.size() < L && c < hi; c++)
+		if (!std::binary_search(cols.begin(), cols.end(), (int32_t) c))
+			cols.insert(std::upper_bound(cols.begin(), cols.end(), (int32_t) c), (int32_t) c);
+	if ((long) cols.size() > L)
+		cols.resize(L);
+}
+
+int
+gen_twin(long m, long n, double avg, double std, double bw_scaled, double skew, double neigh, double crs,
+		unsigned long seed, int pattern, spmv_host_csr * out)
+{
+	memset(out, 0, sizeof(*out));
+	if (m <= 0 || n <= 0 || avg < 0)
+	{
+		set_error("bad twin parameters");
+		return 1;
+	}
+	std::vector<long> len((size_t) m);
+	#pragma omp parallel for schedule(static, 4096)
+	for (long i = 0; i < m; i++)
+	{
+		Rng g(seed, 2 * (uint64_t) i);
+		len[i] = row_length(g, avg, std, n);
+	}
+	// skew: max row = avg*(1+skew); put a ladder max, max/2, max/4, ... on rows spread over the matrix
+	long maxlen = std::min((long) floor(avg * (1.0 + skew) + 0.5), n);
+	if (skew > 3.0)
+	{
+		long L = maxlen;
+		for (int k = 0; L > 2 * (avg + 3 * std) && k < 24; k++, L = L * 2 / 3)
+		{
+			Rng g(seed ^ 0xABCDEF, (uint64_t) k);
+			len[g.below(m)] = L;
+		}
+	}
+	else
+	{
+		long cur = *std::max_element(len.begin(), len.end());
+		if (maxlen > cur)
+			len[m / 2] = maxlen;
+	}
+	long nnz = 0;
+	for (long i = 0; i < m; i++)
+		nnz += len[i];
+	if (nnz >= 0x7fffffffL)
+	{
+		set_error("twin would have %ld non-zeros (int32 limit)", nnz);
+		return 1;
+	}
+	if (alloc_csr(out, m, n, nnz))
+		return 1;
+	out->row_ptr[0] = 0;
+	for (long i = 0; i < m; i++)
+		out->row_ptr[i + 1] = out->row_ptr[i] + (int32_t) len[i];
+	// p(extend run): each extension adds 2 to the neighbour count of its two ends -> avg_num_neighbours ~ 2p/(1-p) capped
+	double p_neigh = neigh / (2.0 + neigh);
+	p_neigh = std::min(std::max(p_neigh, 0.0), 0.95);
+	const double p_crs = std::min(std::max(crs, 0.0), 0.98);
+	// rows are generated in blocks so that "previous row" is available without a serial dependency across blocks
+	const long BLK = 256;
+	#pragma omp parallel
+	{
+		std::vector<int32_t> cols, prev;
+		#pragma omp for schedule(dynamic, 16)
+		for (long b = 0; b < (m + BLK - 1) / BLK; b++)
+		{
+			prev.clear();
+			for (long i = b * BLK; i < std::min(m, (b + 1) * BLK); i++)
+			{
+				Rng g(seed, 2 * (uint64_t) i + 1);
+				long L = out->row_ptr[i + 1] - out->row_ptr[i];
+				// very long rows span the whole matrix
+				double bw = (L > 8 * (avg + 1)) ? 1.0 : bw_scaled;
+				fill_row(g, i, m, n, L, bw, p_neigh, (L > 8 * (avg + 1)) ? 0.0 : p_crs, prev.data(), (long) prev.size(), cols);
+				// fill_row guarantees exactly L columns whenever the window holds L of them; otherwise pad from 0 up
+				for (int32_t c = 0; (long) cols.size() < L; c++)
+					if (!std::binary_search(cols.begin(), cols.end(), c))
+						cols.insert(std::upper_bound(cols.begin(), cols.end(), c), c);
+				int32_t * ci = out->col_idx + out->row_ptr[i];
+				double * va = out->values + out->row_ptr[i];
+				for (long k = 0; k < L; k++)
+				{
+					ci[k] = cols[k];
+					va[k] = pattern ? 1.0 : g.uniform(-1.0, 1.0);
+				}
+				prev = cols;
+			}
+		}
+	}
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------- KKT
+static inline double
+sym_value(uint64_t seed, long i, long j)
+{
+	long a = std::min(i, j), b = std::max(i, j);
+	Rng g(seed, (uint64_t) a * 0x100000001B3ull + (uint64_t) b);
+	return (i == j) ? 4.0 : g.uniform(-1.0, 1.0);
+}
+
+struct Grid {
+	long N, N2, n1, n2, S;
+	inline int stencil7(long g, long * out) const      // in-bounds 7-point neighbours of g, ascending
+	{
+		long z = g / N2, y = (g / N) % N, x = g % N;
+		int k = 0;
+		if (z > 0) out[k++] = g - N2;
+		if (y > 0) out[k++] = g - N;
+		if (x > 0) out[k++] = g - 1;
+		out[k++] = g;
+		if (x < N - 1) out[k++] = g + 1;
+		if (y < N - 1) out[k++] = g + N;
+		if (z < N - 1) out[k++] = g + N2;
+		return k;
+	}
+	inline int stencil27(long g, long * out) const     // ascending
+	{
+		long z = g / N2, y = (g / N) % N, x = g % N;
+		int k = 0;
+		for (long dz = -1; dz <= 1; dz++)
+			for (long dy = -1; dy <= 1; dy++)
+				for (long dx = -1; dx <= 1; dx++)
+				{
+					long zz = z + dz, yy = y + dy, xx = x + dx;
+					if (zz < 0 || zz >= N || yy < 0 || yy >= N || xx < 0 || xx >= N)
+						continue;
+					out[k++] = zz * N2 + yy * N + xx;
+				}
+		return k;
+	}
+	inline long gk(long k) const { return k % n1; }                    // grid point of constraint row k
+	inline long w(long g) const { return (g + S) % n1; }               // half-domain shift
+	inline long winv(long g) const { return (g - S % n1 + n1) % n1; }
+	// columns of constraint row k (grid indices), ascending
+	inline int a_row(long k, long * out) const
+	{
+		long t[14];
+		int c = stencil7(gk(k), t);
+		c += stencil7(w(gk(k)), t + c);
+		std::sort(t, t + c);
+		c = (int) (std::unique(t, t + c) - t);
+		memcpy(out, t, c * sizeof(long));
+		return c;
+	}
+	// constraint rows k whose A-row touches grid point g, ascending
+	inline int a_col(long g, long * out) const
+	{
+		long h[14], t[28];
+		int c = stencil7(g, h);
+		long s7[7];
+		int c2 = stencil7(g, s7);
+		for (int q = 0; q < c2; q++)
+			h[c++] = winv(s7[q]);
+		// h: grid points p with g in stencil7(p) (symmetric) or g in stencil7(w(p))
+		int k = 0;
+		for (int q = 0; q < c; q++)
+		{
+			t[k++] = h[q];
+			if (h[q] + n1 < n2)
+				t[k++] = h[q] + n1;
+		}
+		std::sort(t, t + k);
+		k = (int) (std::unique(t, t + k) - t);
+		memcpy(out, t, k * sizeof(long));
+		return k;
+	}
+};
+
+static int
+make_grid(long N, Grid & G)
+{
+	if (N < 4)
+	{
+		set_error("KKT grid edge must be >= 4");
+		return 1;
+	}
+	G.N = N; G.N2 = N * N; G.n1 = N * N * N; G.n2 = G.n1 + 6 * N * N; G.S = G.n1 / 2 + N / 3;
+	return 0;
+}
+
+static inline int
+kkt_row_len(const Grid & G, long i)
+{
+	long tmp[32];
+	if (i < G.n1)
+		return G.stencil27(i, tmp) + G.a_col(i, tmp);
+	return G.a_row(i - G.n1, tmp);
+}
+
+// global row_ptr only (m+1 entries): lets every rank of a row-partitioned run find its block without building A
+int
+gen_kkt_row_ptr(long N, int32_t * row_ptr, long * m_out, long * nnz_out)
+{
+	Grid G;
+	if (make_grid(N, G))
+		return 1;
+	const long m = G.n1 + G.n2;
+	if (m_out)
+		*m_out = m;
+	if (!row_ptr)
+		return 0;
+	#pragma omp parallel for schedule(static, 8192)
+	for (long i = 0; i < m; i++)
+		row_ptr[i + 1] = kkt_row_len(G, i);
+	long acc = 0;
+	row_ptr[0] = 0;
+	for (long i = 0; i < m; i++)
+	{
+		acc += row_ptr[i + 1];
+		if (acc >= 0x7fffffffL)
+		{
+			set_error("KKT matrix too large for int32 indices");
+			return 1;
+		}
+		row_ptr[i + 1] = (int32_t) acc;
+	}
+	if (nnz_out)
+		*nnz_out = acc;
+	return 0;
+}
+
+// rows [r0,r1) of the KKT matrix as a local CSR (row_ptr starts at 0, columns global)
+int
+gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out)
+{
+	memset(out, 0, sizeof(*out));
+	Grid G;
+	if (make_grid(N, G))
+		return 1;
+	const long m = G.n1 + G.n2;
+	if (r0 < 0 || r1 > m || r0 > r1)
+	{
+		set_error("bad KKT row block [%ld,%ld) of %ld", r0, r1, m);
+		return 1;
+	}
+	const long lm = r1 - r0;
+	std::vector<int32_t> len((size_t) std::max<long>(lm, 1));
+	#pragma omp parallel for schedule(static, 8192)
+	for (long i = 0; i < lm; i++)
+		len[i] = kkt_row_len(G, r0 + i);
+	long nnz = 0;
+	for (long i = 0; i < lm; i++)
+		nnz += len[i];
+	if (nnz >= 0x7fffffffL || m + nnz >= 0x7fffffffL)
+	{
+		set_error("KKT block too large for int32 indices (rows=%ld nnz=%ld)", lm, nnz);
+		return 1;
+	}
+	if (alloc_csr(out, lm, m, nnz))
+		return 1;
+	out->row_ptr[0] = 0;
+	for (long i = 0; i < lm; i++)
+		out->row_ptr[i + 1] = out->row_ptr[i] + len[i];
+	#pragma omp parallel for schedule(static, 8192)
+	for (long li = 0; li < lm; li++)
+	{
+		const long i = r0 + li;
+		long tmp[32];
+		int32_t * ci = out->col_idx + out->row_ptr[li];
+		double * va = out->values + out->row_ptr[li];
+		int k = 0;
+		if (i < G.n1)
+		{
+			int c = G.stencil27(i, tmp);
+			for (int q = 0; q < c; q++, k++)
+				ci[k] = (int32_t) tmp[q];
+			c = G.a_col(i, tmp);
+			for (int q = 0; q < c; q++, k++)
+				ci[k] = (int32_t) (G.n1 + tmp[q]);
+		}
+		else
+		{
+			int c = G.a_row(i - G.n1, tmp);
+			for (int q = 0; q < c; q++, k++)
+				ci[k] = (int32_t) tmp[q];
+		}
+		for (int q = 0; q < k; q++)
+			va[q] = sym_value(seed, i, ci[q]);
+	}
+	return 0;
+}
+
+int
+gen_kkt(long N, unsigned long seed, spmv_host_csr * out)
+{
+	Grid G;
+	if (make_grid(N, G))
+		return 1;
+	return gen_kkt_block(N, seed, 0, G.n1 + G.n2, out);
+}
+
+// Row-partitioned runs keep x as P slices padded to a common length (one equal-sized RCCL allgather, no compaction
+// pass): column c owned by part p moves to p*padded + (c - offsets[p]).
+int
+remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, long padded)
+{
+	long bad = 0;
+	#pragma omp parallel for reduction(+ : bad)
+	for (long j = 0; j < nnz; j++)
+	{
+		long c = col_idx[j];
+		long lo = 0, hi = parts;          // largest p with offsets[p] <= c
+		while (hi - lo > 1)
+		{
+			long mid = (lo + hi) / 2;
+			if (offsets[mid] <= c)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		long v = lo * padded + (c - offsets[lo]);
+		if (c < offsets[0] || c >= offsets[parts] || c - offsets[lo] >= padded || v >= 0x7fffffffL)
+			bad++;
+		else
+			col_idx[j] = (int32_t) v;
+	}
+	if (bad)
+	{
+		set_error("%ld column indices outside the partition / padded slice", bad);
+		return 1;
+	}
+	return 0;
+}
+
+}  // namespace spmv_host

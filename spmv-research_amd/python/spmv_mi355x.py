@@ -47,6 +47,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C spmv-research_amd` "
                                "(__graft_entry__.build()). There is no CPU fallback.")
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 and refuses to initialise ("No HIP GPUs
+        # are available") when the system copy was loaded first. Loading torch's first lets both share it.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         L.spmv_mi355x_last_error.restype = C.c_char_p
         L.spmv_mi355x_format_name.restype = C.c_char_p
