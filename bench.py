@@ -140,22 +140,17 @@ def main():
         r0, r1 = 0, m
     offsets = None
     if world > 1:
-        # nnz-balanced contiguous row blocks: lib/parallel_util.h:156-184 applied with W = number of GPUs
-        offsets = np.zeros(world + 1, np.int64)
-        for p in range(world):
-            s, e = H.partition_prefix_sums(world, p, row_ptr_g, m, nnz_total)
-            offsets[p], offsets[p + 1] = s, e
+        import spmv_dist as D
+        offsets = D.row_partition(row_ptr_g, world)          # nnz-balanced contiguous row blocks (parallel_util.h:156-184)
         r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
         if workload == "nlpkkt240":
             blk = H.gen_kkt_block(kkt_edge(args.scale), r0, r1)
         else:
-            s, e = int(row_ptr_g[r0]), int(row_ptr_g[r1])
-            blk = dict(m=r1 - r0, n=n, nnz=e - s, row_ptr=(row_ptr_g[r0:r1 + 1] - s).astype(np.int32),
-                       col_idx=A["col_idx"][s:e].copy(), values=A["values"][s:e].copy())
+            blk = D.local_block(row_ptr_g, A["col_idx"], A["values"], offsets, rank)
             del A
         assert m == n, "row-partitioned allgather(x) assumes a square matrix (x slices follow the row blocks)"
-        padded = int((np.diff(offsets).max() + 63) // 64 * 64)
-        H.remap_columns(blk["col_idx"], offsets, padded)      # x lives as `world` slices padded to a common length
+        padded = D.padded_len(offsets)
+        D.to_padded_columns(blk["col_idx"], offsets, padded)   # x lives as `world` slices padded to a common length
         n_x = padded * world
     else:
         padded = n

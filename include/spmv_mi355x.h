@@ -44,7 +44,9 @@ enum {
 	                                  sell_c_s.cpp:39-131                                                                  */
 	SPMV_MI355X_COO          = 4,  /* row-sorted COO, segmented reduction; replaces mkl_coo.cpp:58-106 /
 	                                  GPU_clean/rocsparse_coo.cpp:88-104,294                                               */
-	SPMV_MI355X_NUM_FORMATS  = 5
+	SPMV_MI355X_CSR_STREAM   = 5,  /* one wavefront per block of R consecutive rows, products staged in LDS (CSR-Stream);
+	                                  replaces the row-block CSR kernels GPU_clean/spmv_subkernel_csr_rocm_adaptive.cpp:76-153 */
+	SPMV_MI355X_NUM_FORMATS  = 6
 };
 
 enum { SPMV_MI355X_F64 = 0, SPMV_MI355X_F32 = 1 };
@@ -54,11 +56,13 @@ typedef struct {
 	int  struct_size;
 	int  device;            /* HIP device ordinal; -1 = the current device                                        */
 	int  lanes_per_row;     /* CSR_VECTOR: 2,4,8,16,32,64; 0 = chosen from mean nnz/row                            */
+	                        /* CSR_STREAM: the same field holds ROWS PER WAVEFRONT (4,8,16,32,64); 0 = auto          */
 	int  block_threads;     /* threads per workgroup (multiple of 64); 0 = 256                                     */
 	int  sell_c;            /* SELL: rows per slice (16, 32 or 64); 0 = 64 (one wavefront = one slice)             */
 	int  sell_sigma;        /* SELL: sort window in rows (multiple of sell_c); 0 = 16384 (sell_c_s.cpp:58-60)      */
 	int  merge_items;       /* MERGE: merge items per thread (5,7,9,11,13); COO: entries per lane (2,4,8); 0 = default */
-	int  xcd_remap;         /* give each of the 8 XCDs a contiguous eighth of the tiles: 0 = auto (on), 1 = on, 2 = off */
+	int  xcd_remap;         /* tile order over the 8 XCDs: 0 = auto, 1 = contiguous work-balanced ranges, 2 = off,
+	                           3 = chunks of 32 tiles dealt round-robin to the XCDs                                */
 	int  nontemporal;       /* matrix streams loaded with the nt policy: 0 = auto (by footprint), 1 = on, 2 = off  */
 	int  reserved0;
 	long row_begin;         /* row block [row_begin,row_end) of the GLOBAL CSR to keep on this device (row-partitioned */

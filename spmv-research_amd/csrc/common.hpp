@@ -25,28 +25,101 @@ constexpr int WAVE = 64;
 constexpr int NUM_XCD = 8;
 
 // --------------------------------------------------------------------------------------- XCD-aware tiling
-// Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2). With remap on, XCD k walks
-// the k-th contiguous eighth of the tiles, so every L2 sees one compact window of x instead of all eight
-// windows interleaved. Speed only: any placement gives the same result. The grid must be launched with
-// xcd_grid(ntiles) blocks; tiles >= ntiles are skipped by the caller.
-__host__ __device__ inline unsigned
-xcd_tiles_per_xcd(unsigned ntiles)
-{
-	return (ntiles + NUM_XCD - 1) / NUM_XCD;
-}
+// Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2; which XCD is not defined, only the
+// grouping). With the map on, XCD group k walks the contiguous tile range [start[k], start[k+1]), so every L2 sees one
+// compact window of x instead of eight interleaved ones. The ranges are balanced by WORK (non-zeros), not by tile
+// count: contiguous eighths of a matrix whose halves differ 3x in row length left half of the chip idle (measured on
+// the nlpkkt240 twin: 4.3 -> 5.0 TB/s from balance alone). Speed only: any placement gives the same result.
+struct XcdMap {
+	unsigned start[NUM_XCD + 1];   // remap == 1: tile range per XCD group (balanced by work)
+	unsigned ntiles;
+	unsigned remap;                // 0 = identity, 1 = contiguous work-balanced ranges, 2 = chunks of XCD_CHUNK tiles dealt
+	                               //     round-robin to the XCD groups (locality inside a chunk, balance by statistics)
+};
 
-__host__ inline unsigned
-xcd_grid(unsigned ntiles, bool remap)
-{
-	return remap ? xcd_tiles_per_xcd(ntiles) * NUM_XCD : ntiles;
-}
+constexpr unsigned XCD_CHUNK = 32;
+
+constexpr unsigned NO_TILE = 0xffffffffu;
 
 __device__ __forceinline__ unsigned
-xcd_tile(unsigned bid, unsigned ntiles, int remap)
+xcd_tile(unsigned bid, const XcdMap & mp)
 {
-	if (!remap)
-		return bid;
-	return (bid % NUM_XCD) * xcd_tiles_per_xcd(ntiles) + bid / NUM_XCD;
+	if (!mp.remap)
+		return bid < mp.ntiles ? bid : NO_TILE;
+	const unsigned k = bid % NUM_XCD;
+	const unsigned i = bid / NUM_XCD;          // i-th block of this XCD group
+	if (mp.remap == 2)
+	{
+		const unsigned t = ((i / XCD_CHUNK) * NUM_XCD + k) * XCD_CHUNK + i % XCD_CHUNK;
+		return t < mp.ntiles ? t : NO_TILE;
+	}
+	const unsigned t = mp.start[k] + i;
+	return t < mp.start[k + 1] ? t : NO_TILE;
+}
+
+// blocks to launch for a map
+inline unsigned
+xcd_grid(const XcdMap & mp)
+{
+	if (!mp.remap)
+		return mp.ntiles;
+	if (mp.remap == 2)
+	{
+		const unsigned span = NUM_XCD * XCD_CHUNK;
+		return (mp.ntiles + span - 1) / span * span;
+	}
+	unsigned mx = 0;
+	for (int k = 0; k < NUM_XCD; k++)
+		mx = mp.start[k + 1] - mp.start[k] > mx ? mp.start[k + 1] - mp.start[k] : mx;
+	return mx * NUM_XCD;
+}
+
+// equal tile counts (tiles of equal work: merge path, COO)
+inline XcdMap
+xcd_map_uniform(unsigned ntiles, int remap)
+{
+	XcdMap mp;
+	mp.ntiles = ntiles;
+	mp.remap = (unsigned) remap;
+	for (int k = 0; k <= NUM_XCD; k++)
+		mp.start[k] = (unsigned) ((unsigned long long) ntiles * k / NUM_XCD);
+	return mp;
+}
+
+// tiles of `units_per_tile` consecutive units (rows, slices) whose cumulative work is prefix[unit] (prefix has
+// num_units+1 entries, e.g. row_ptr): boundary k = first tile whose starting prefix reaches k/8 of the total
+template <typename P>
+inline XcdMap
+xcd_map_balanced(const P * prefix, long num_units, long units_per_tile, int remap)
+{
+	XcdMap mp;
+	const long ntiles = (num_units + units_per_tile - 1) / units_per_tile;
+	mp.ntiles = (unsigned) ntiles;
+	mp.remap = (unsigned) remap;
+	const double total = (double) (prefix[num_units] - prefix[0]);
+	mp.start[0] = 0;
+	for (int k = 1; k < NUM_XCD; k++)
+	{
+		const double target = total * k / NUM_XCD;
+		long lo = 0, hi = ntiles;          // first tile t with work before it >= target
+		while (lo < hi)
+		{
+			long mid = (lo + hi) / 2;
+			long u = mid * units_per_tile;
+			if (u > num_units)
+				u = num_units;
+			if ((double) (prefix[u] - prefix[0]) >= target)
+				hi = mid;
+			else
+				lo = mid + 1;
+		}
+		mp.start[k] = (unsigned) lo;
+	}
+	mp.start[NUM_XCD] = (unsigned) ntiles;
+	for (int k = 1; k <= NUM_XCD; k++)
+		if (mp.start[k] < mp.start[k - 1])
+			mp.start[k] = mp.start[k - 1];
+	return mp;
 }
 
 // ------------------------------------------------------------------------------------------------- loads

@@ -26,10 +26,10 @@ template <typename T, int K, bool NT>
 __global__ __launch_bounds__(COO_BLOCK) void
 coo_kernel(const int * __restrict__ rowind, const int * __restrict__ col, const T * __restrict__ val,
 		const T * __restrict__ x, T * __restrict__ y, long nnz, int num_waves,
-		int * __restrict__ carry_row, T * __restrict__ carry_val, int beta, unsigned ntiles, int remap)
+		int * __restrict__ carry_row, T * __restrict__ carry_val, int beta, XcdMap map)
 {
-	unsigned tile = xcd_tile(blockIdx.x, ntiles, remap);
-	if (tile >= ntiles)
+	unsigned tile = xcd_tile(blockIdx.x, map);
+	if (tile == NO_TILE)
 		return;
 	const int lane = threadIdx.x % WAVE;
 	const int w = tile * COO_WAVES + threadIdx.x / WAVE;
@@ -136,8 +136,7 @@ static int
 coo_launch_k(const int * rowind, const int * col, const void * val, const void * x, void * y, int m, long nnz, int num_waves,
 		int * carry_row, void * carry_val, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
-	unsigned ntiles = (unsigned) ((num_waves + COO_WAVES - 1) / COO_WAVES);
-	unsigned grid = xcd_grid(ntiles, cfg.remap);
+	unsigned grid = xcd_grid(cfg.map);
 	if (grid_out)
 		*grid_out = grid;
 	if (!cfg.beta && m > 0)
@@ -146,10 +145,10 @@ coo_launch_k(const int * rowind, const int * col, const void * val, const void *
 		return 0;
 	if (cfg.nt)
 		hipLaunchKernelGGL((coo_kernel<T, K, true>), dim3(grid), dim3(COO_BLOCK), 0, stream, rowind, col, (const T *) val,
-				(const T *) x, (T *) y, nnz, num_waves, carry_row, (T *) carry_val, cfg.beta, ntiles, cfg.remap);
+				(const T *) x, (T *) y, nnz, num_waves, carry_row, (T *) carry_val, cfg.beta, cfg.map);
 	else
 		hipLaunchKernelGGL((coo_kernel<T, K, false>), dim3(grid), dim3(COO_BLOCK), 0, stream, rowind, col, (const T *) val,
-				(const T *) x, (T *) y, nnz, num_waves, carry_row, (T *) carry_val, cfg.beta, ntiles, cfg.remap);
+				(const T *) x, (T *) y, nnz, num_waves, carry_row, (T *) carry_val, cfg.beta, cfg.map);
 	HIP_TRY(hipGetLastError());
 	unsigned fgrid = (unsigned) ((num_waves + COO_BLOCK - 1) / COO_BLOCK);
 	hipLaunchKernelGGL((coo_fixup_kernel<T>), dim3(fgrid), dim3(COO_BLOCK), 0, stream, carry_row, (const T *) carry_val,

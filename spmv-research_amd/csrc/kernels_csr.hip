@@ -20,10 +20,10 @@ constexpr int CSR_BLOCK = 256;
 template <typename T, bool NT>
 __global__ __launch_bounds__(CSR_BLOCK) void
 csr_scalar_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
-		const T * __restrict__ x, T * __restrict__ y, int m, int beta, unsigned ntiles, int remap)
+		const T * __restrict__ x, T * __restrict__ y, int m, int beta, XcdMap map)
 {
-	unsigned tile = xcd_tile(blockIdx.x, ntiles, remap);
-	if (tile >= ntiles)
+	unsigned tile = xcd_tile(blockIdx.x, map);
+	if (tile == NO_TILE)
 		return;
 	int row = tile * CSR_BLOCK + threadIdx.x;
 	if (row >= m)
@@ -39,11 +39,11 @@ csr_scalar_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col
 template <typename T, int G, bool NT>
 __global__ __launch_bounds__(CSR_BLOCK) void
 csr_vector_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
-		const T * __restrict__ x, T * __restrict__ y, int m, int beta, unsigned ntiles, int remap)
+		const T * __restrict__ x, T * __restrict__ y, int m, int beta, XcdMap map)
 {
 	constexpr int ROWS_PER_BLOCK = CSR_BLOCK / G;
-	unsigned tile = xcd_tile(blockIdx.x, ntiles, remap);
-	if (tile >= ntiles)
+	unsigned tile = xcd_tile(blockIdx.x, map);
+	if (tile == NO_TILE)
 		return;
 	const int row = tile * ROWS_PER_BLOCK + threadIdx.x / G;
 	const int lane = threadIdx.x % G;
@@ -95,18 +95,17 @@ static int
 csr_scalar_dispatch(const int * row_ptr, const int * col, const void * val, const void * x, void * y, int m,
 		const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
-	unsigned ntiles = (unsigned) (((long) m + CSR_BLOCK - 1) / CSR_BLOCK);
-	unsigned grid = xcd_grid(ntiles, cfg.remap);
+	unsigned grid = xcd_grid(cfg.map);
 	if (grid_out)
 		*grid_out = grid;
 	if (grid == 0)
 		return 0;
 	if (cfg.nt)
 		hipLaunchKernelGGL((csr_scalar_kernel<T, true>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col, (const T *) val,
-				(const T *) x, (T *) y, m, cfg.beta, ntiles, cfg.remap);
+				(const T *) x, (T *) y, m, cfg.beta, cfg.map);
 	else
 		hipLaunchKernelGGL((csr_scalar_kernel<T, false>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col, (const T *) val,
-				(const T *) x, (T *) y, m, cfg.beta, ntiles, cfg.remap);
+				(const T *) x, (T *) y, m, cfg.beta, cfg.map);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -124,19 +123,17 @@ static int
 csr_vector_launch_g(const int * row_ptr, const int * col, const void * val, const void * x, void * y, int m,
 		const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
-	constexpr int ROWS_PER_BLOCK = CSR_BLOCK / G;
-	unsigned ntiles = (unsigned) (((long) m + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-	unsigned grid = xcd_grid(ntiles, cfg.remap);
+	unsigned grid = xcd_grid(cfg.map);
 	if (grid_out)
 		*grid_out = grid;
 	if (grid == 0)
 		return 0;
 	if (cfg.nt)
 		hipLaunchKernelGGL((csr_vector_kernel<T, G, true>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col,
-				(const T *) val, (const T *) x, (T *) y, m, cfg.beta, ntiles, cfg.remap);
+				(const T *) val, (const T *) x, (T *) y, m, cfg.beta, cfg.map);
 	else
 		hipLaunchKernelGGL((csr_vector_kernel<T, G, false>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col,
-				(const T *) val, (const T *) x, (T *) y, m, cfg.beta, ntiles, cfg.remap);
+				(const T *) val, (const T *) x, (T *) y, m, cfg.beta, cfg.map);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

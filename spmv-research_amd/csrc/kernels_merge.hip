@@ -65,7 +65,7 @@ template <typename T, int IPT, bool NT>
 __global__ __launch_bounds__(MERGE_BLOCK) void
 merge_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
 		const T * __restrict__ x, T * __restrict__ y, int m, const int * __restrict__ coords,
-		int * __restrict__ carry_row, T * __restrict__ carry_val, int beta, unsigned ntiles, int remap)
+		int * __restrict__ carry_row, T * __restrict__ carry_val, int beta, XcdMap map)
 {
 	constexpr int TILE = MERGE_BLOCK * IPT;
 	// rows_in_tile + nnz_in_tile <= TILE: products first, row ends behind them, in one buffer
@@ -73,8 +73,8 @@ merge_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, con
 	__shared__ T s_wave_val[MERGE_BLOCK / WAVE];
 	__shared__ int s_wave_flag[MERGE_BLOCK / WAVE];
 
-	const unsigned tile = xcd_tile(blockIdx.x, ntiles, remap);
-	if (tile >= ntiles)
+	const unsigned tile = xcd_tile(blockIdx.x, map);
+	if (tile == NO_TILE)
 		return;
 	const int tid = threadIdx.x;
 	const int * __restrict__ row_end = row_ptr + 1;
@@ -265,17 +265,17 @@ merge_launch_ipt(const int * row_ptr, const int * col, const void * val, const v
 		const int * coords, int * carry_row, void * carry_val, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
 	unsigned ntiles = (unsigned) num_tiles;
-	unsigned grid = xcd_grid(ntiles, cfg.remap);
+	unsigned grid = xcd_grid(cfg.map);
 	if (grid_out)
 		*grid_out = grid;
 	if (grid == 0)
 		return 0;
 	if (cfg.nt)
 		hipLaunchKernelGGL((merge_kernel<T, IPT, true>), dim3(grid), dim3(MERGE_BLOCK), 0, stream, row_ptr, col, (const T *) val,
-				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, ntiles, cfg.remap);
+				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, cfg.map);
 	else
 		hipLaunchKernelGGL((merge_kernel<T, IPT, false>), dim3(grid), dim3(MERGE_BLOCK), 0, stream, row_ptr, col, (const T *) val,
-				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, ntiles, cfg.remap);
+				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, cfg.map);
 	HIP_TRY(hipGetLastError());
 	unsigned fgrid = (ntiles + MERGE_BLOCK - 1) / MERGE_BLOCK;
 	hipLaunchKernelGGL((merge_fixup_kernel<T>), dim3(fgrid), dim3(MERGE_BLOCK), 0, stream, carry_row, (const T *) carry_val,

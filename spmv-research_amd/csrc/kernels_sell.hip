@@ -27,10 +27,10 @@ template <typename T, int C, bool NT>
 __global__ __launch_bounds__(SELL_BLOCK) void
 sell_kernel(const int64_t * __restrict__ slice_ptr, const int * __restrict__ col, const T * __restrict__ val,
 		const int * __restrict__ row_of_sorted, const T * __restrict__ x, T * __restrict__ y,
-		int m, int num_slices, int beta, unsigned ntiles, int remap)
+		int m, int num_slices, int beta, XcdMap map)
 {
-	unsigned tile = xcd_tile(blockIdx.x, ntiles, remap);
-	if (tile >= ntiles)
+	unsigned tile = xcd_tile(blockIdx.x, map);
+	if (tile == NO_TILE)
 		return;
 	const int lane = threadIdx.x % WAVE;
 	const int slice = tile * SELL_WAVES + threadIdx.x / WAVE;
@@ -61,8 +61,23 @@ sell_kernel(const int64_t * __restrict__ slice_ptr, const int * __restrict__ col
 			s0 = fma_t<T>(v2, x2, s0);
 			s0 = fma_t<T>(v3, x3, s0);
 		}
-		for (; p < p_e; p += WAVE)
-			s0 = fma_t<T>(ld_stream<NT>(val + p), x[ld_stream<NT>(col + p)], s0);
+		if (p < p_e)
+		{
+			// 1..3 leftover steps as ONE masked batch (a serial tail would expose a full memory round trip per step)
+			const bool k1 = p + WAVE < p_e, k2 = p + 2 * WAVE < p_e;
+			const int c0 = ld_stream<NT>(col + p);
+			const int c1 = k1 ? ld_stream<NT>(col + p + WAVE) : 0;
+			const int c2 = k2 ? ld_stream<NT>(col + p + 2 * WAVE) : 0;
+			const T v0 = ld_stream<NT>(val + p);
+			const T v1 = k1 ? ld_stream<NT>(val + p + WAVE) : T(0);
+			const T v2 = k2 ? ld_stream<NT>(val + p + 2 * WAVE) : T(0);
+			const T x0 = x[c0];
+			const T x1 = k1 ? x[c1] : T(0);
+			const T x2 = k2 ? x[c2] : T(0);
+			s0 = fma_t<T>(v0, x0, s0);
+			if (k1) s0 = fma_t<T>(v1, x1, s0);
+			if (k2) s0 = fma_t<T>(v2, x2, s0);
+		}
 	}
 	else
 	{
@@ -81,8 +96,19 @@ sell_kernel(const int64_t * __restrict__ slice_ptr, const int * __restrict__ col
 			s2 = fma_t<T>(v2, x[c2], s2);
 			s3 = fma_t<T>(v3, x[c3], s3);
 		}
-		for (; p < p_e; p += WAVE)
-			s0 = fma_t<T>(ld_stream<NT>(val + p), x[ld_stream<NT>(col + p)], s0);
+		if (p < p_e)
+		{
+			const bool k1 = p + WAVE < p_e, k2 = p + 2 * WAVE < p_e;
+			const int c0 = ld_stream<NT>(col + p);
+			const int c1 = k1 ? ld_stream<NT>(col + p + WAVE) : 0;
+			const int c2 = k2 ? ld_stream<NT>(col + p + 2 * WAVE) : 0;
+			const T v0 = ld_stream<NT>(val + p);
+			const T v1 = k1 ? ld_stream<NT>(val + p + WAVE) : T(0);
+			const T v2 = k2 ? ld_stream<NT>(val + p + 2 * WAVE) : T(0);
+			s0 = fma_t<T>(v0, x[c0], s0);
+			if (k1) s1 = fma_t<T>(v1, x[c1], s1);
+			if (k2) s2 = fma_t<T>(v2, x[c2], s2);
+		}
 		s0 = (s0 + s1) + (s2 + s3);
 		// combine the TPR = 64/C column phases of each row: lanes r, r+C, r+2C, ...
 		#pragma unroll
@@ -105,18 +131,17 @@ static int
 sell_launch_c(const int64_t * slice_ptr, const int * col, const void * val, const int * row_of_sorted, const void * x, void * y,
 		int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
-	unsigned ntiles = (unsigned) ((num_slices + SELL_WAVES - 1) / SELL_WAVES);
-	unsigned grid = xcd_grid(ntiles, cfg.remap);
+	unsigned grid = xcd_grid(cfg.map);
 	if (grid_out)
 		*grid_out = grid;
 	if (grid == 0)
 		return 0;
 	if (cfg.nt)
 		hipLaunchKernelGGL((sell_kernel<T, C, true>), dim3(grid), dim3(SELL_BLOCK), 0, stream, slice_ptr, col, (const T *) val,
-				row_of_sorted, (const T *) x, (T *) y, m, num_slices, cfg.beta, ntiles, cfg.remap);
+				row_of_sorted, (const T *) x, (T *) y, m, num_slices, cfg.beta, cfg.map);
 	else
 		hipLaunchKernelGGL((sell_kernel<T, C, false>), dim3(grid), dim3(SELL_BLOCK), 0, stream, slice_ptr, col, (const T *) val,
-				row_of_sorted, (const T *) x, (T *) y, m, num_slices, cfg.beta, ntiles, cfg.remap);
+				row_of_sorted, (const T *) x, (T *) y, m, num_slices, cfg.beta, cfg.map);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

@@ -7,16 +7,28 @@
 namespace spmv {
 
 struct LaunchCfg {
-	int remap;          // XCD-aware tile order
+	XcdMap map;         // tile order over the 8 XCDs (built at conversion time for the kernel's tile geometry)
 	int nt;             // nontemporal matrix streams
 	int beta;           // 0: y = A x, 1: y += A x
 };
+
+// tile geometry of each kernel family (units per workgroup), needed to build the XCD map
+inline long csr_scalar_rows_per_tile() { return 256; }
+inline long csr_vector_rows_per_tile(int lanes_per_row) { return 256 / lanes_per_row; }
+inline long csr_stream_rows_per_tile(int rows_per_wave) { return 4L * rows_per_wave; }
+inline long sell_slices_per_tile() { return 4; }
+inline long coo_waves_per_tile() { return 4; }
 
 // ---- CSR (kernels_csr.hip)
 int launch_csr_scalar(bool f32, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
 		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 int launch_csr_vector(bool f32, int lanes_per_row, const int * row_ptr, const int * col, const void * val,
 		const void * x, void * y, int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+
+// ---- CSR-Stream: one wavefront per block of R consecutive rows (kernels_csr_stream.hip)
+int csr_stream_cap();                                                  // non-zeros a row block may hold on the LDS path
+int launch_csr_stream(bool f32, int rows_per_wave, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
 // ---- merge-path CSR (kernels_merge.hip)
 int merge_tile_items(bool f32, int items_per_thread);                 // merge items (rows + nnz) per workgroup

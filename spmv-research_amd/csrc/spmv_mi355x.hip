@@ -37,7 +37,8 @@ struct spmv_mi355x_matrix {
 	int device = 0;
 	bool f32 = false;
 	size_t vbytes = 8;
-	LaunchCfg cfg{1, 0, 0};
+	LaunchCfg cfg{};
+	int remap = 1;
 
 	// CSR family
 	int * d_row_ptr = nullptr;
@@ -236,6 +237,7 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 	}
 	A->sell_slices = num_slices;
 	A->sell_nnz_ext = nnz_ext;
+	A->cfg.map = xcd_map_balanced(slice_ptr.data(), num_slices, sell_slices_per_tile(), A->remap);
 	if (dev_alloc(&A->d_slice_ptr, (size_t) num_slices + 1))
 		return 1;
 	HIP_TRY(hipMemcpy(A->d_slice_ptr, slice_ptr.data(), ((size_t) num_slices + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -453,7 +455,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 	}
 
 	// ---- launch policy
-	A->cfg.remap = (o.xcd_remap == 2) ? 0 : 1;
+	A->remap = (o.xcd_remap == 2) ? 0 : (o.xcd_remap == 3) ? 2 : 1;
 	const double stream_bytes = (double) lnnz * (A->vbytes + 4);
 	A->cfg.nt = (o.nontemporal == 1) ? 1 : (o.nontemporal == 2) ? 0 : (stream_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
 	A->cfg.beta = 0;
@@ -465,6 +467,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 		case SPMV_MI355X_CSR_SCALAR:
 		case SPMV_MI355X_CSR_VECTOR:
 		case SPMV_MI355X_CSR_MERGE:
+		case SPMV_MI355X_CSR_STREAM:
 		{
 			rc = upload_ints(rp, (size_t) lm + 1, &A->d_row_ptr) || upload_ints(ci, (size_t) lnnz, &A->d_col) ||
 			     upload_values(A, va, (size_t) lnnz, &A->d_val);
@@ -473,8 +476,31 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 			A->mem_footprint = A->csr_mem_footprint;
 			if (format == SPMV_MI355X_CSR_SCALAR)
 			{
+				A->cfg.map = xcd_map_balanced(rp, lm, csr_scalar_rows_per_tile(), A->remap);
 				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_SCALAR_%s", pf);
 				snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_scalar_kernel");
+			}
+			else if (format == SPMV_MI355X_CSR_STREAM)
+			{
+				int R = o.lanes_per_row;
+				if (R == 0)
+				{
+					// largest power of two with R * mean nnz/row <= 60% of the LDS strip, so typical blocks stay on the LDS path
+					double mean = lm > 0 ? (double) lnnz / lm : 0;
+					R = 64;
+					while (R > 4 && R * mean > 0.6 * csr_stream_cap())
+						R /= 2;
+				}
+				if (R != 4 && R != 8 && R != 16 && R != 32 && R != 64)
+				{
+					set_error("csr_stream: rows per wavefront (lanes_per_row) must be 4,8,16,32 or 64 (got %d)", R);
+					rc = 1;
+					break;
+				}
+				A->lanes_per_row = R;
+				A->cfg.map = xcd_map_balanced(rp, lm, csr_stream_rows_per_tile(R), A->remap);
+				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_STREAM_r%d_%s", R, pf);
+				snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_stream_kernel");
 			}
 			else if (format == SPMV_MI355X_CSR_VECTOR)
 			{
@@ -488,6 +514,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 					break;
 				}
 				A->lanes_per_row = G;
+				A->cfg.map = xcd_map_balanced(rp, lm, csr_vector_rows_per_tile(G), A->remap);
 				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_VECTOR_g%d_%s", G, pf);
 				snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_vector_kernel");
 			}
@@ -512,6 +539,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 					rc = 1;
 					break;
 				}
+				A->cfg.map = xcd_map_uniform((unsigned) A->merge_num_tiles, A->remap);      // tiles hold equal work by construction
 				A->mem_footprint += 2.0 * (A->merge_num_tiles + 1) * 4;
 				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_MERGE_i%d_%s", A->merge_ipt, pf);
 				snprintf(A->kernel_name, sizeof(A->kernel_name), "merge_kernel");
@@ -563,6 +591,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 			A->coo_num_waves = (int) ((lnnz + per_wave - 1) / per_wave);
 			rc = dev_alloc(&A->d_carry_row, (size_t) A->coo_num_waves) ||
 			     dev_alloc_bytes(&A->d_carry_val, (size_t) A->coo_num_waves * A->vbytes);
+			A->cfg.map = xcd_map_uniform((unsigned) ((A->coo_num_waves + coo_waves_per_tile() - 1) / coo_waves_per_tile()), A->remap);
 			A->mem_footprint = (double) lnnz * (A->vbytes + 8);
 			snprintf(A->format_name, sizeof(A->format_name), "MI355X_COO_k%d_%s", A->coo_k, pf);
 			snprintf(A->kernel_name, sizeof(A->kernel_name), "coo_kernel");
@@ -612,6 +641,9 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 			break;
 		case SPMV_MI355X_CSR_VECTOR:
 			rc = launch_csr_vector(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
+			break;
+		case SPMV_MI355X_CSR_STREAM:
+			rc = launch_csr_stream(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_CSR_MERGE:
 			rc = launch_merge(A->f32, A->merge_ipt, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, (int) A->nnz,

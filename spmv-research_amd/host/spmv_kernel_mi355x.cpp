@@ -6,7 +6,7 @@
 // Mirrors spmv_kernels/spmv_kernel_template.cpp:20-93 (a Matrix_Format subclass + csr_to_format +
 // statistics_print_labels). The kernel family is chosen at compile time with -DSPMV_MI355X_FORMAT=<id> (one executable
 // per format, like every other backend) or at run time with the environment variable SPMV_MI355X_FORMAT
-// (csr_scalar | csr_vector | csr_merge | sell_c_sigma | coo); tunables via SPMV_MI355X_LANES_PER_ROW, _SELL_C,
+// (csr_scalar | csr_vector | csr_merge | sell_c_sigma | coo | csr_stream); tunables via SPMV_MI355X_LANES_PER_ROW, _SELL_C,
 // _SELL_SIGMA, _MERGE_ITEMS. Errors end the process the way the reference's error() does (lib/debug.h:83-135).
 
 #include <stdio.h>
@@ -37,11 +37,11 @@ chosen_format()
 	const char * s = getenv("SPMV_MI355X_FORMAT");
 	if (s && *s)
 	{
-		static const char * names[] = {"csr_scalar", "csr_vector", "csr_merge", "sell_c_sigma", "coo"};
+		static const char * names[] = {"csr_scalar", "csr_vector", "csr_merge", "sell_c_sigma", "coo", "csr_stream"};
 		for (int i = 0; i < SPMV_MI355X_NUM_FORMATS; i++)
 			if (!strcmp(s, names[i]))
 				return i;
-		mi355x_error("SPMV_MI355X_FORMAT='%s' is not one of csr_scalar, csr_vector, csr_merge, sell_c_sigma, coo", s);
+		mi355x_error("SPMV_MI355X_FORMAT='%s' is not one of csr_scalar, csr_vector, csr_merge, sell_c_sigma, coo, csr_stream", s);
 	}
 	#ifdef SPMV_MI355X_FORMAT
 		return SPMV_MI355X_FORMAT;

@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libspmv_mi355x.so")
 
-CSR_SCALAR, CSR_VECTOR, CSR_MERGE, SELL_C_SIGMA, COO = range(5)
+CSR_SCALAR, CSR_VECTOR, CSR_MERGE, SELL_C_SIGMA, COO, CSR_STREAM = range(6)
 FORMATS = {"csr_scalar": CSR_SCALAR, "csr_vector": CSR_VECTOR, "csr_merge": CSR_MERGE,
-           "sell_c_sigma": SELL_C_SIGMA, "coo": COO}
+           "sell_c_sigma": SELL_C_SIGMA, "coo": COO, "csr_stream": CSR_STREAM}
 F64, F32 = 0, 1
 
 

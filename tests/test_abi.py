@@ -1,0 +1,73 @@
+"""The C-ABI shared objects load and export every symbol the headers in include/ declare (no compute calls: there
+is no GPU in the CPU test tier), and the product fails loudly — never falls back — without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spmv_(?:mi355x|host)_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("header,module", [("spmv_mi355x.h", "spmv_mi355x"), ("spmv_host.h", "spmv_host")])
+def test_every_declared_symbol_is_exported(header, module):
+    mod = __import__(module)
+    lib = mod.lib()
+    assert isinstance(lib, ctypes.CDLL)
+    names = declared_functions(header)
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/{header} but not exported by {mod.LIB_PATH}"
+    assert sorted(mod.SYMBOLS) == names, "python binding symbol list out of date with the header"
+
+
+def test_opts_struct_layout_matches_header():
+    import spmv_mi355x as E
+    # 10 ints, 4 longs, 2 ints (include/spmv_mi355x.h: spmv_mi355x_opts)
+    assert ctypes.sizeof(E.Opts) == 10 * 4 + 4 * 8 + 2 * 4
+    assert E.Opts.row_begin.offset == 40 and E.Opts.col_filter_mode.offset == 72
+
+
+@pytest.mark.skipif(has_gpu(), reason="CPU tier only: checks the no-device failure mode")
+def test_no_cpu_fallback_without_a_device():
+    import spmv_mi355x as E
+    assert E.device_count() == 0
+    rp = np.array([0, 1], np.int32)
+    with pytest.raises(E.SpmvError, match="no HIP device|no CPU fallback"):
+        E.Matrix(rp, np.array([0], np.int32), np.array([1.0]), 1, 1, "csr_vector")
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under spmv-research_amd/ may include, link or import it."""
+    pkg = os.path.join(ROOT, "spmv-research_amd")
+    for d, _, files in os.walk(pkg):
+        if os.sep + "build" in d or os.sep + "lib" in d or os.sep + "bin" in d or "__pycache__" in d:
+            continue
+        for f in files:
+            if f.endswith((".so", ".o")):
+                continue
+            text = open(os.path.join(d, f), errors="ignore").read()
+            assert "oracle" not in text.lower() or f == "spmv_kernel_mi355x.cpp" and False, f"{os.path.join(d, f)} mentions the oracle"
+    import subprocess
+    for so in ("libspmv_mi355x.so", "libspmv_host.so"):
+        out = subprocess.run(["ldd", os.path.join(pkg, "lib", so)], capture_output=True, text=True).stdout
+        assert "liboracle" not in out and "libref_" not in out
+
+
+def test_driver_prints_the_reference_csv_header():
+    import subprocess
+    exe = os.path.join(ROOT, "spmv-research_amd", "bin", "spmv_mi355x_bench")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    # column list of bench_spmv.cpp:417-445 + check_accuracy_labels :94-105
+    want = ("matrix_name,num_threads,csr_m,csr_n,csr_nnz,symmetry,time,time_iter_min,time_iter_median,time_iter_max,"
+            "gflops,csr_mem_footprint,W_avg,J_estimated,format_name,m,n,nnz,mem_footprint,mem_ratio,num_loops,"
+            "spmv_mae,spmv_max_ae,spmv_mse,spmv_mape,spmv_smape,spmv_lnQ_error,spmv_mlare,spmv_gmare")
+    assert r.stderr.strip() == want

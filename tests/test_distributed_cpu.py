@@ -1,0 +1,74 @@
+"""world_size-2 gloo rehearsal (CPU) of the multi-GPU path of bench.py: nnz-balanced row blocks, padded x slices filled
+by ONE in-place all_gather_into_tensor, local-column / remote-column split with y = A_loc x + A_rem x, y blocks
+concatenated in rank order = global row order. The per-block arithmetic here is the ORACLE (there is no CPU product
+path); what is under test is the host logic the GPU run shares: spmv_dist, spmv_host.remap_columns, the collective."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "spmv-research_amd", "python"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    import oracle as orc
+    import spmv_dist as D
+    import spmv_host as H
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A = H.gen_kkt(9)                                           # same matrix on every rank (deterministic)
+        m = n = A["m"]
+        x = np.random.default_rng(14).uniform(-1, 1, n)
+        off = D.row_partition(A["row_ptr"], world)
+        r0, r1 = int(off[rank]), int(off[rank + 1])
+        blk = D.local_block(A["row_ptr"], A["col_idx"], A["values"], off, rank)
+        padded = D.padded_len(off)
+        D.to_padded_columns(blk["col_idx"], off, padded)
+        x_full = torch.zeros(world * padded, dtype=torch.float64)
+        x_loc = x_full[rank * padded:(rank + 1) * padded]
+        x_loc[:r1 - r0] = torch.from_numpy(x[r0:r1])
+        dist.all_gather_into_tensor(x_full, x_loc)                 # in place: own slice already sits inside x_full
+        xp = x_full.numpy()
+        np.testing.assert_array_equal(xp, D.scatter_x_padded(x, off, padded))
+        # local / remote column split of the block (what the two GPU handles hold)
+        c0, c1 = rank * padded, rank * padded + (r1 - r0)
+        inside = (blk["col_idx"] >= c0) & (blk["col_idx"] < c1)
+        rows = np.repeat(np.arange(blk["m"]), np.diff(blk["row_ptr"]))
+
+        def sub(mask):
+            rp = np.zeros(blk["m"] + 1, np.int32)
+            np.add.at(rp, rows[mask] + 1, 1)
+            return np.cumsum(rp).astype(np.int32), blk["col_idx"][mask], blk["values"][mask]
+        y = orc.csr_spmv(*sub(inside), xp) + orc.csr_spmv(*sub(~inside), xp)
+        ypad = torch.zeros(padded, dtype=torch.float64)             # validation only, not on the data path
+        ypad[:r1 - r0] = torch.from_numpy(y)
+        ys = [torch.zeros(padded, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ys, ypad)
+        if rank == 0:
+            y_all = torch.cat([ys[p][:int(off[p + 1] - off[p])] for p in range(world)]).numpy()
+            y_ref = orc.csr_spmv(A["row_ptr"], A["col_idx"], A["values"], x)
+            absrow = orc.csr_spmv(A["row_ptr"], A["col_idx"], np.abs(A["values"]), np.abs(x))
+            q.put(float(np.max(np.abs(y_all - y_ref) / absrow)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_row_partition_allgather_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) <= 1e-12

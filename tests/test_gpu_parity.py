@@ -26,6 +26,10 @@ VARIANTS = [
     ("csr_vector", {"lanes_per_row": 32}, False),
     ("csr_vector", {"lanes_per_row": 64}, False),      # the literal "one wavefront per row" of config 2
     ("csr_vector", {}, False),                          # auto
+    ("csr_stream", {}, False),
+    ("csr_stream", {"lanes_per_row": 4}, False),
+    ("csr_stream", {"lanes_per_row": 16}, False),
+    ("csr_stream", {"lanes_per_row": 64}, False),
     ("csr_merge", {}, False),
     ("csr_merge", {"merge_items": 5}, False),
     ("csr_merge", {"merge_items": 13}, False),
@@ -170,7 +174,7 @@ def test_beta_accumulate_and_row_blocks(eng, oracle):
     y_ref = oracle.csr_spmv(rp, ci, a, x)
     absrow = oracle.csr_spmv(rp, ci, np.abs(a), np.abs(x))
     xd = torch.from_numpy(x).cuda()
-    for fmt in ("csr_scalar", "csr_vector", "csr_merge", "sell_c_sigma", "coo"):
+    for fmt in ("csr_scalar", "csr_vector", "csr_stream", "csr_merge", "sell_c_sigma", "coo"):
         parts = 3
         y_all = []
         for p in range(parts):

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Run ONE (workload, format) a few times on the GPU — the unit that rocprofv3 passes wrap."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "spmv-research_amd", "python"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="nlpkkt240")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--format", default="csr_stream")
+    ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--opt", action="append", default=[], help="key=value")
+    args = ap.parse_args()
+    import torch
+    import spmv_host as H
+    import spmv_mi355x as E
+    A = H.gen_named(args.workload, args.scale)
+    npd = np.float64 if args.dtype == "f64" else np.float32
+    td = torch.float64 if args.dtype == "f64" else torch.float32
+    opts = {k: int(v) for k, v in (o.split("=") for o in args.opt)}
+    M = E.Matrix(A["row_ptr"], A["col_idx"], A["values"], A["m"], A["n"], args.format, npd, **opts)
+    x = torch.from_numpy(np.random.default_rng(14).uniform(-1, 1, A["n"]).astype(npd)).cuda()
+    y = torch.zeros(A["m"] + 64, dtype=td, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ms = M.time_device(x.data_ptr(), y.data_ptr(), args.iters, s)
+    vb = 8 if args.dtype == "f64" else 4
+    B = A["nnz"] * (vb + 4) + (A["m"] + 1) * 4 + (A["n"] + A["m"]) * vb
+    print(f"{args.workload} {M.format_name} {ms*1e3:.1f} us/launch {B/ms/1e6:.1f} GB/s algorithmic_bytes={B}")
+
+
+if __name__ == "__main__":
+    main()
