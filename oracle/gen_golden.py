@@ -168,6 +168,16 @@ def make_cases(rng):
     r, c = rand_pattern(rng, 20, m, 90)
     v = rng.uniform(-1, 1, len(r))
     cases["empty_tail"] = f"%%MatrixMarket matrix coordinate real general\n{m} {m} {len(r)}\n" + coo_lines(r, c, v)
+    # 15. pattern + skew-symmetric: dummy values are filled AFTER the expansion, so the mirrored entries are +1.0
+    m = 72
+    r, c = rand_pattern(rng, m, m, 260, lower_only=True, strict_lower=True)
+    cases["pattern_skew"] = (f"%%MatrixMarket matrix coordinate pattern skew-symmetric\n{m} {m} {len(r)}\n" + coo_lines(r, c))
+    # 16. integer symmetric with negative values (sign/width conversions)
+    m = 88
+    r, c = rand_pattern(rng, m, m, 420, lower_only=True)
+    v = rng.integers(-2000000, 2000000, len(r))
+    cases["integer_symmetric"] = (f"%%MatrixMarket matrix coordinate integer symmetric\n{m} {m} {len(r)}\n"
+                                  + coo_lines(r, c, v, fmtv=lambda z: str(int(z))))
     return cases
 
 

@@ -30,6 +30,10 @@ int csr_stream_cap();                                                  // non-ze
 int launch_csr_stream(bool f32, int rows_per_wave, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
 		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
+int csr_stream_t_cap(int rows_per_wave);                               // same, transposed-consumption variant
+int launch_csr_stream_t(bool f32, int rows_per_wave, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+
 // ---- merge-path CSR (kernels_merge.hip)
 int merge_tile_items(bool f32, int items_per_thread);                 // merge items (rows + nnz) per workgroup
 int launch_merge_search(const int * row_ptr, int m, int nnz, int tile_items, int num_tiles, int * coords /* [2*(num_tiles+1)] */,

@@ -45,6 +45,7 @@ struct spmv_mi355x_matrix {
 	int * d_col = nullptr;
 	void * d_val = nullptr;
 	int lanes_per_row = 0;
+	int stream_mode = 0;                   // CSR_STREAM: 1 = products in LDS (row-major gather), 2 = (val,col) in LDS, lane-per-row walk
 	// merge
 	int merge_ipt = 0, merge_tile = 0, merge_num_tiles = 0;
 	int * d_coords = nullptr;
@@ -146,12 +147,24 @@ upload_ints(const int * src, size_t count, int ** d_out)
 static int
 pick_lanes_per_row(double mean)
 {
-	if (mean <= 3) return 2;
-	if (mean <= 6) return 4;
+	// measured on the five BASELINE.json twins (profiles/sweep_r01.md): 8..16 lanes win from 5.6 to 64 nnz/row — a
+	// wider group only adds idle lanes and butterfly steps, a narrower one serialises the row
+	if (mean <= 4) return 4;
 	if (mean <= 12) return 8;
-	if (mean <= 24) return 16;
-	if (mean <= 48) return 32;
+	if (mean <= 128) return 16;
+	if (mean <= 512) return 32;
 	return 64;
+}
+
+// auto tile order: contiguous work-balanced ranges keep each XCD's L2 on one window of x (best for small and skewed
+// matrices); for many-tile matrices chunks of 32 tiles dealt round-robin balance row-count-bound kernels better
+// (nlpkkt240 twin: csr_vector +26 %, csr_stream +12 %, SELL +2 %; pwtk/soc-LiveJournal1 twins prefer the ranges)
+static int
+resolve_remap(int requested, long ntiles)
+{
+	if (requested >= 0)
+		return requested;
+	return ntiles >= 8192 ? 2 : 1;
 }
 
 // ---------------------------------------------------------------------------------------------------- SELL build
@@ -237,7 +250,8 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 	}
 	A->sell_slices = num_slices;
 	A->sell_nnz_ext = nnz_ext;
-	A->cfg.map = xcd_map_balanced(slice_ptr.data(), num_slices, sell_slices_per_tile(), A->remap);
+	A->cfg.map = xcd_map_balanced(slice_ptr.data(), num_slices, sell_slices_per_tile(),
+			resolve_remap(A->remap, (num_slices + sell_slices_per_tile() - 1) / sell_slices_per_tile()));
 	if (dev_alloc(&A->d_slice_ptr, (size_t) num_slices + 1))
 		return 1;
 	HIP_TRY(hipMemcpy(A->d_slice_ptr, slice_ptr.data(), ((size_t) num_slices + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -455,7 +469,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 	}
 
 	// ---- launch policy
-	A->remap = (o.xcd_remap == 2) ? 0 : (o.xcd_remap == 3) ? 2 : 1;
+	A->remap = (o.xcd_remap == 2) ? 0 : (o.xcd_remap == 3) ? 2 : (o.xcd_remap == 1) ? 1 : -1;   // -1 = auto, resolved per kernel
 	const double stream_bytes = (double) lnnz * (A->vbytes + 4);
 	A->cfg.nt = (o.nontemporal == 1) ? 1 : (o.nontemporal == 2) ? 0 : (stream_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
 	A->cfg.beta = 0;
@@ -476,31 +490,50 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 			A->mem_footprint = A->csr_mem_footprint;
 			if (format == SPMV_MI355X_CSR_SCALAR)
 			{
-				A->cfg.map = xcd_map_balanced(rp, lm, csr_scalar_rows_per_tile(), A->remap);
+				A->cfg.map = xcd_map_balanced(rp, lm, csr_scalar_rows_per_tile(), resolve_remap(A->remap, lm / csr_scalar_rows_per_tile()));
 				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_SCALAR_%s", pf);
 				snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_scalar_kernel");
 			}
 			else if (format == SPMV_MI355X_CSR_STREAM)
 			{
 				int R = o.lanes_per_row;
+				A->stream_mode = (o.stream_mode == 1) ? 1 : 2;
+				const double mean = lm > 0 ? (double) lnnz / lm : 0;
 				if (R == 0)
 				{
 					// largest power of two with R * mean nnz/row <= 60% of the LDS strip, so typical blocks stay on the LDS path
-					double mean = lm > 0 ? (double) lnnz / lm : 0;
 					R = 64;
-					while (R > 4 && R * mean > 0.6 * csr_stream_cap())
-						R /= 2;
+					if (A->stream_mode == 1)
+						while (R > 4 && R * mean > 0.6 * csr_stream_cap())
+							R /= 2;
+					else
+					{
+						// largest R whose row blocks overflow the LDS strip (slow path) in at most 0.5 % of the cases
+						for (R = 64; R > 8; R /= 2)
+						{
+							const long cap = csr_stream_t_cap(R);
+							long over = 0, blocks = (lm + R - 1) / R;
+							#pragma omp parallel for reduction(+ : over)
+							for (long b = 0; b < blocks; b++)
+								over += (rp[std::min(lm, (b + 1) * R)] - rp[b * R]) > cap;
+							if (over * 200 <= blocks)
+								break;
+						}
+					}
 				}
-				if (R != 4 && R != 8 && R != 16 && R != 32 && R != 64)
+				const bool okR = (A->stream_mode == 1) ? (R == 4 || R == 8 || R == 16 || R == 32 || R == 64)
+				                                       : (R == 8 || R == 16 || R == 32 || R == 64);
+				if (!okR)
 				{
-					set_error("csr_stream: rows per wavefront (lanes_per_row) must be 4,8,16,32 or 64 (got %d)", R);
+					set_error("csr_stream: rows per wavefront (lanes_per_row) must be %s (got %d)",
+							A->stream_mode == 1 ? "4,8,16,32 or 64" : "8,16,32 or 64", R);
 					rc = 1;
 					break;
 				}
 				A->lanes_per_row = R;
-				A->cfg.map = xcd_map_balanced(rp, lm, csr_stream_rows_per_tile(R), A->remap);
-				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_STREAM_r%d_%s", R, pf);
-				snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_stream_kernel");
+				A->cfg.map = xcd_map_balanced(rp, lm, csr_stream_rows_per_tile(R), resolve_remap(A->remap, lm / csr_stream_rows_per_tile(R)));
+				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_STREAM%s_r%d_%s", A->stream_mode == 2 ? "T" : "", R, pf);
+				snprintf(A->kernel_name, sizeof(A->kernel_name), A->stream_mode == 2 ? "csr_stream_t_kernel" : "csr_stream_kernel");
 			}
 			else if (format == SPMV_MI355X_CSR_VECTOR)
 			{
@@ -514,7 +547,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 					break;
 				}
 				A->lanes_per_row = G;
-				A->cfg.map = xcd_map_balanced(rp, lm, csr_vector_rows_per_tile(G), A->remap);
+				A->cfg.map = xcd_map_balanced(rp, lm, csr_vector_rows_per_tile(G), resolve_remap(A->remap, lm / csr_vector_rows_per_tile(G)));
 				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_VECTOR_g%d_%s", G, pf);
 				snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_vector_kernel");
 			}
@@ -539,7 +572,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 					rc = 1;
 					break;
 				}
-				A->cfg.map = xcd_map_uniform((unsigned) A->merge_num_tiles, A->remap);      // tiles hold equal work by construction
+				A->cfg.map = xcd_map_uniform((unsigned) A->merge_num_tiles, resolve_remap(A->remap, 0));      // tiles hold equal work by construction
 				A->mem_footprint += 2.0 * (A->merge_num_tiles + 1) * 4;
 				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_MERGE_i%d_%s", A->merge_ipt, pf);
 				snprintf(A->kernel_name, sizeof(A->kernel_name), "merge_kernel");
@@ -591,7 +624,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 			A->coo_num_waves = (int) ((lnnz + per_wave - 1) / per_wave);
 			rc = dev_alloc(&A->d_carry_row, (size_t) A->coo_num_waves) ||
 			     dev_alloc_bytes(&A->d_carry_val, (size_t) A->coo_num_waves * A->vbytes);
-			A->cfg.map = xcd_map_uniform((unsigned) ((A->coo_num_waves + coo_waves_per_tile() - 1) / coo_waves_per_tile()), A->remap);
+			A->cfg.map = xcd_map_uniform((unsigned) ((A->coo_num_waves + coo_waves_per_tile() - 1) / coo_waves_per_tile()), resolve_remap(A->remap, 0));
 			A->mem_footprint = (double) lnnz * (A->vbytes + 8);
 			snprintf(A->format_name, sizeof(A->format_name), "MI355X_COO_k%d_%s", A->coo_k, pf);
 			snprintf(A->kernel_name, sizeof(A->kernel_name), "coo_kernel");
@@ -643,7 +676,9 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 			rc = launch_csr_vector(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_CSR_STREAM:
-			rc = launch_csr_stream(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
+			rc = (A->stream_mode == 2)
+			     ? launch_csr_stream_t(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid)
+			     : launch_csr_stream(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_CSR_MERGE:
 			rc = launch_merge(A->f32, A->merge_ipt, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, (int) A->nnz,

@@ -17,8 +17,10 @@ def variants(dts):
     v = [("csr_scalar", {})]
     for g in (2, 4, 8, 16, 32, 64):
         v.append(("csr_vector", {"lanes_per_row": g}))
-    for r in (4, 8, 16, 32, 64):
+    for r in (8, 16, 32, 64):
         v.append(("csr_stream", {"lanes_per_row": r}))
+    for r in (8, 16):
+        v.append(("csr_stream", {"lanes_per_row": r, "stream_mode": 1}))
     for i in (5, 7, 9, 11, 13):
         v.append(("csr_merge", {"merge_items": i}))
     for c in (16, 32, 64):
