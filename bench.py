@@ -100,11 +100,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    local_rank %= torch.cuda.device_count()       # a gloo rehearsal may put several ranks on one GPU; RCCL runs get one each
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     workload = args.workload
     fmt = args.format or DEFAULT_FORMAT.get(workload, "csr_vector")
@@ -181,6 +185,9 @@ def main():
     else:
         x_loc = x_full[rank * padded:(rank + 1) * padded]         # in-place allgather: own slice lives inside x_full
         x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
+    # RCCL gathers in place (send buffer = own slice of the receive buffer); gloo stages through the host and wants a
+    # separate send buffer
+    x_send = x_loc if (world == 1 or args.backend == "nccl") else x_loc.clone()
     y = torch.full((lm + 64,), 1.0, dtype=t_dtype, device="cuda")  # driver canary (bench_spmv.cpp:606-609)
     compute = torch.cuda.current_stream()
     sp = compute.cuda_stream
@@ -189,12 +196,12 @@ def main():
         if world == 1:
             mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
         elif args.overlap:
-            work = dist.all_gather_into_tensor(x_full, x_loc, async_op=True)
+            work = dist.all_gather_into_tensor(x_full, x_send, async_op=True)
             mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)      # local columns: only the own slice of x
             work.wait()
             mats[1].spmv_device(x_full.data_ptr(), y.data_ptr(), 1, sp)      # remote columns, y += ...
         else:
-            dist.all_gather_into_tensor(x_full, x_loc)
+            dist.all_gather_into_tensor(x_full, x_send)
             mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
 
     def barrier():
@@ -295,6 +302,12 @@ def main():
         snnz = int(rp[rs])
         tb = orc.time_csr_spmv(rp[:rs + 1], ci[:snnz], va[:snnz], x_host.astype(np.float64), cores,
                                min_loops=5, min_runtime=args.cpu_baseline_seconds)
+        # the baseline must have done the work: its y agrees with the GPU's on the sampled rows
+        ys = np.asarray(tb["y"], np.float64)
+        chk = [i for i in samp if i < rs]
+        if chk:
+            dmax = float(np.max(np.abs(ys[chk] - yh[chk]) / np.maximum(np.abs(yh[chk]), 1e-300)))
+            assert dmax < 1e-9 or dts == "f32", f"CPU baseline result differs from the GPU result ({dmax})"
         result["cpu_baseline"] = {"value": round(2.0 * snnz / tb["median"] / 1e9, 3), "unit": "GFLOP/s",
                                   "cores": cores, "kind": "port", "sample": sample,
                                   "median_s": tb["median"], "loops": tb["loops"],

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Turn the PMC passes of tools/collect_traffic.sh into profiles/traffic_<round>.json (read by bench.py).
+
+HBM bytes per launch of the dominant kernel:
+  read  = 32*RDREQ_32B + 128*RDREQ_128B + 64*(RDREQ - RDREQ_32B - RDREQ_128B)      (TCC_EA0 request counters, exact sizes)
+          cross-check: FETCH_SIZE [KiB] counts every request as 64 B on gfx950, i.e. exactly half of a 128-B stream
+          (MI355X_MICROARCH.md, HBM section) -> 2*FETCH_SIZE*1024 is reported beside it;
+  write = WRITE_SIZE [KiB] * 1024.
+Infinity-Cache hits are counted by these fabric-side counters, so for matrices that fit the 256 MiB cache the number is
+"bytes through the L2's memory side", not DRAM bytes.
+"""
+import csv, glob, json, os, sys, collections
+
+
+def kernel_means(d):
+    acc = collections.defaultdict(list)
+    dur = {}
+    name = ""
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = r["Kernel_Name"]
+                if "spmv::" not in k or "fixup" in k or "search" in k or "expand" in k:
+                    continue
+                name = k.split("(")[0].replace("void spmv::", "")
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                dur[(f, r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    out = {c: sum(v) / len(v) for c, v in acc.items()}
+    out["_kernel"] = name
+    out["_duration_us"] = sum(dur.values()) / max(len(dur), 1) / 1e3
+    return out
+
+
+def main():
+    root, outp = sys.argv[1], sys.argv[2]
+    records = []
+    for tagdir in sorted(glob.glob(os.path.join(root, "*"))):
+        tag = os.path.basename(tagdir)
+        m = {}
+        for p in sorted(glob.glob(os.path.join(tagdir, "pass*"))):
+            km = kernel_means(p)
+            durs = m.get("_durs", [])
+            durs.append(km.pop("_duration_us"))
+            m.update(km)
+            m["_durs"] = durs
+        if "FETCH_SIZE" not in m:
+            continue
+        parts = tag.split("_")
+        rd = m.get("TCC_EA0_RDREQ_sum")
+        if rd is not None:
+            r32, r128 = m.get("TCC_EA0_RDREQ_32B_sum", 0.0), m.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+            read_bytes = 32 * r32 + 128 * r128 + 64 * (rd - r32 - r128)
+        else:
+            read_bytes = 2 * m["FETCH_SIZE"] * 1024
+        write_bytes = m.get("WRITE_SIZE", 0.0) * 1024
+        rec = dict(tag=tag, kernel=m.get("_kernel"), kernel_us_under_profiler=sum(m["_durs"]) / len(m["_durs"]),
+                   fetch_size_kib=m["FETCH_SIZE"], write_size_kib=m.get("WRITE_SIZE"),
+                   read_bytes_from_request_sizes=read_bytes, read_bytes_2x_fetch_size=2 * m["FETCH_SIZE"] * 1024,
+                   write_bytes=write_bytes, hbm_bytes_per_launch=int(read_bytes + write_bytes),
+                   counters={k: v for k, v in m.items() if not k.startswith("_")})
+        records.append(rec)
+        print(tag, rec["kernel"], "read %.3f GB (2xFETCH %.3f GB) write %.3f GB" % (read_bytes / 1e9, rec["read_bytes_2x_fetch_size"] / 1e9, write_bytes / 1e9))
+    # workload/format/dtype keys for bench.py: filled from a side file written next to the passes
+    for rec in records:
+        w, rest = rec["tag"].split("_", 1)
+        for wl in ("soc-LiveJournal1", "nlpkkt240", "scircuit", "cant", "pwtk"):
+            if rec["tag"].startswith(wl + "_"):
+                w, rest = wl, rec["tag"][len(wl) + 1:]
+        for fmt in ("csr_scalar", "csr_vector", "csr_stream", "csr_merge", "sell_c_sigma", "coo"):
+            if rest.startswith(fmt):
+                rec["workload"], rec["format"] = w, fmt
+                rec["dtype"] = "f32" if "_f32" in rest else "f64"
+                rec["opts"] = rest[len(fmt):].replace("_f64", "").replace("_f32", "").strip("_")
+    with open(outp, "w") as f:
+        json.dump(dict(records=records), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
