@@ -64,8 +64,10 @@ typedef struct {
 	int  xcd_remap;         /* tile order over the 8 XCDs: 0 = auto, 1 = contiguous work-balanced ranges, 2 = off,
 	                           3 = chunks of 32 tiles dealt round-robin to the XCDs                                */
 	int  nontemporal;       /* matrix streams loaded with the nt policy: 0 = auto (by footprint), 1 = on, 2 = off  */
-	int  stream_mode;       /* CSR_STREAM: 0 = auto (2), 1 = products staged in LDS, 2 = (value,column) pairs staged in LDS
-	                           and one lane group walking each row (coalesced x gathers; R = 64 is bit-exact)      */
+	int  stream_mode;       /* CSR_STREAM: 0 = auto (3); 1 = products staged in LDS (row-major x gather); 2 = (value,column)
+	                           pairs staged in LDS through registers, lanes walk rows (coalesced x gathers); 3 = the same with
+	                           the global->LDS copy done by LDS-DMA (global_load_lds). With 64 rows per wave 2 and 3 are
+	                           bit-exact                                                                              */
 	long row_begin;         /* row block [row_begin,row_end) of the GLOBAL CSR to keep on this device (row-partitioned */
 	long row_end;           /*   multi-GPU, §8e); 0,0 = all rows. x stays full length n; y has row_end-row_begin rows. */
 	long col_begin;         /* optional column filter [col_begin,col_end) used for the local/remote split that lets    */

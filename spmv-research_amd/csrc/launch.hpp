@@ -34,6 +34,12 @@ int csr_stream_t_cap(int rows_per_wave);                               // same, 
 int launch_csr_stream_t(bool f32, int rows_per_wave, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
 		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
+int csr_stream_d_cap(int rows_per_wave);
+long csr_stream_d_rows_per_tile(int rows_per_wave);                    // rows per workgroup (workgroup size varies with R)                               // same, LDS-DMA variant
+int launch_csr_stream_d(bool f32, int rows_per_wave, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+constexpr int STREAM_SLACK = 512;                                      // entries the LDS-DMA copy may read past a row block
+
 // ---- merge-path CSR (kernels_merge.hip)
 int merge_tile_items(bool f32, int items_per_thread);                 // merge items (rows + nnz) per workgroup
 int launch_merge_search(const int * row_ptr, int m, int nnz, int tile_items, int num_tiles, int * coords /* [2*(num_tiles+1)] */,

@@ -111,8 +111,10 @@ free_all(spmv_mi355x_matrix * A)
 static int
 upload_values(spmv_mi355x_matrix * A, const double * v, size_t count, void ** d_out)
 {
-	if (dev_alloc_bytes(d_out, count * A->vbytes))
+	// STREAM_SLACK spare entries: the LDS-DMA row-block copy reads whole 1 KiB chunks (kernels_csr_stream.hip)
+	if (dev_alloc_bytes(d_out, (count + STREAM_SLACK) * A->vbytes))
 		return 1;
+	HIP_TRY(hipMemset((char *) *d_out + count * A->vbytes, 0, STREAM_SLACK * A->vbytes));
 	if (count == 0)
 		return 0;
 	if (!A->f32)
@@ -137,8 +139,9 @@ upload_values(spmv_mi355x_matrix * A, const double * v, size_t count, void ** d_
 static int
 upload_ints(const int * src, size_t count, int ** d_out)
 {
-	if (dev_alloc(d_out, count))
+	if (dev_alloc(d_out, count + STREAM_SLACK))
 		return 1;
+	HIP_TRY(hipMemset(*d_out + count, 0, STREAM_SLACK * sizeof(int)));
 	if (count)
 		HIP_TRY(hipMemcpy(*d_out, src, count * sizeof(int), hipMemcpyHostToDevice));
 	return 0;
@@ -497,21 +500,42 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 			else if (format == SPMV_MI355X_CSR_STREAM)
 			{
 				int R = o.lanes_per_row;
-				A->stream_mode = (o.stream_mode == 1) ? 1 : 2;
 				const double mean = lm > 0 ? (double) lnnz / lm : 0;
+				int mode = o.stream_mode;
+				if (mode < 1 || mode > 3)
+				{
+					// The lane-per-row walk (modes 2/3) pays when neighbouring rows touch neighbouring columns (stencil /
+					// FEM matrices: one x gather instruction then hits a few lines). Estimate that on a sample of rows; with
+					// scattered columns (graphs) the row-major product staging of mode 1 is the better CSR-Stream.
+					long similar = 0, tried = 0;
+					const long stride = std::max<long>(1, lm / 4096);
+					for (long i = 0; i + 1 < lm; i += stride)
+					{
+						if (rp[i + 1] == rp[i] || rp[i + 2] == rp[i + 1])
+							continue;
+						tried++;
+						long d = (long) ci[rp[i + 1]] - ci[rp[i]];
+						similar += (d >= -2 && d <= 2);
+					}
+					mode = (tried == 0 || 4 * similar >= tried) ? 3 : 1;      // twins: stencil/FEM 0.8-1.0, circuit 0.38, social graph 0.13
+				}
+				A->stream_mode = mode;
 				if (R == 0)
 				{
-					// largest power of two with R * mean nnz/row <= 60% of the LDS strip, so typical blocks stay on the LDS path
-					R = 64;
-					if (A->stream_mode == 1)
+					if (mode == 1)
+					{
+						// largest power of two with R * mean nnz/row <= 60% of the LDS strip
+						R = 16;                     // more rows per wave only lengthen the per-lane LDS walk (measured)
 						while (R > 4 && R * mean > 0.6 * csr_stream_cap())
 							R /= 2;
+					}
 					else
 					{
-						// largest R whose row blocks overflow the LDS strip (slow path) in at most 0.5 % of the cases
-						for (R = 64; R > 8; R /= 2)
+						// largest R <= 16 whose row blocks overflow the LDS strip (slow path) in at most 0.5 % of the cases:
+						// measured optimum is a block of ~150-450 non-zeros per wave (profiles/sweep_r01.md)
+						for (R = (mode == 3 ? 16 : 32); R > (mode == 3 ? 4 : 8); R /= 2)
 						{
-							const long cap = csr_stream_t_cap(R);
+							const long cap = mode == 3 ? csr_stream_d_cap(R) : csr_stream_t_cap(R);
 							long over = 0, blocks = (lm + R - 1) / R;
 							#pragma omp parallel for reduction(+ : over)
 							for (long b = 0; b < blocks; b++)
@@ -521,19 +545,24 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 						}
 					}
 				}
-				const bool okR = (A->stream_mode == 1) ? (R == 4 || R == 8 || R == 16 || R == 32 || R == 64)
+				const bool okR = (A->stream_mode != 2) ? (R == 4 || R == 8 || R == 16 || R == 32 || R == 64)
 				                                       : (R == 8 || R == 16 || R == 32 || R == 64);
 				if (!okR)
 				{
 					set_error("csr_stream: rows per wavefront (lanes_per_row) must be %s (got %d)",
-							A->stream_mode == 1 ? "4,8,16,32 or 64" : "8,16,32 or 64", R);
+							A->stream_mode != 2 ? "4,8,16,32 or 64" : "8,16,32 or 64", R);
 					rc = 1;
 					break;
 				}
 				A->lanes_per_row = R;
-				A->cfg.map = xcd_map_balanced(rp, lm, csr_stream_rows_per_tile(R), resolve_remap(A->remap, lm / csr_stream_rows_per_tile(R)));
-				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_STREAM%s_r%d_%s", A->stream_mode == 2 ? "T" : "", R, pf);
-				snprintf(A->kernel_name, sizeof(A->kernel_name), A->stream_mode == 2 ? "csr_stream_t_kernel" : "csr_stream_kernel");
+				{
+					const long rpt = A->stream_mode == 3 ? csr_stream_d_rows_per_tile(R) : csr_stream_rows_per_tile(R);
+					A->cfg.map = xcd_map_balanced(rp, lm, rpt, resolve_remap(A->remap, lm / rpt));
+				}
+				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_STREAM%s_r%d_%s",
+						A->stream_mode == 3 ? "D" : A->stream_mode == 2 ? "T" : "", R, pf);
+				snprintf(A->kernel_name, sizeof(A->kernel_name), A->stream_mode == 3 ? "csr_stream_d_kernel" :
+						A->stream_mode == 2 ? "csr_stream_t_kernel" : "csr_stream_kernel");
 			}
 			else if (format == SPMV_MI355X_CSR_VECTOR)
 			{
@@ -676,7 +705,9 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 			rc = launch_csr_vector(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_CSR_STREAM:
-			rc = (A->stream_mode == 2)
+			rc = (A->stream_mode == 3)
+			     ? launch_csr_stream_d(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid)
+			     : (A->stream_mode == 2)
 			     ? launch_csr_stream_t(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid)
 			     : launch_csr_stream(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
 			break;

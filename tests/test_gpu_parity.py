@@ -27,9 +27,14 @@ VARIANTS = [
     ("csr_vector", {"lanes_per_row": 64}, False),      # the literal "one wavefront per row" of config 2
     ("csr_vector", {}, False),                          # auto
     ("csr_stream", {}, False),
-    ("csr_stream", {"lanes_per_row": 64}, True),                          # (val,col) in LDS, lane per row: bit-exact
+    ("csr_stream", {"lanes_per_row": 64}, False),                         # LDS-DMA, lane per row (exact only while the block fits the strip)
     ("csr_stream", {"lanes_per_row": 32}, False),
+    ("csr_stream", {"lanes_per_row": 16}, False),
     ("csr_stream", {"lanes_per_row": 8}, False),
+    ("csr_stream", {"lanes_per_row": 4}, False),
+    ("csr_stream", {"stream_mode": 2, "lanes_per_row": 64}, True),        # register-staged (val,col) in LDS
+    ("csr_stream", {"stream_mode": 2, "lanes_per_row": 32}, False),
+    ("csr_stream", {"stream_mode": 2, "lanes_per_row": 8}, False),
     ("csr_stream", {"stream_mode": 1, "lanes_per_row": 4}, False),        # products in LDS
     ("csr_stream", {"stream_mode": 1, "lanes_per_row": 16}, False),
     ("csr_stream", {"stream_mode": 1, "lanes_per_row": 64}, False),

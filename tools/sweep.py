@@ -14,11 +14,13 @@ sys.path.insert(0, os.path.join(ROOT, "spmv-research_amd", "python"))
 
 
 def variants(dts):
-    v = [("csr_scalar", {})]
+    v = [("csr_scalar", {}), ("csr_vector", {}), ("csr_stream", {}), ("csr_merge", {}), ("sell_c_sigma", {}), ("coo", {})]   # auto
     for g in (2, 4, 8, 16, 32, 64):
         v.append(("csr_vector", {"lanes_per_row": g}))
-    for r in (8, 16, 32, 64):
+    for r in (4, 8, 16, 32, 64):
         v.append(("csr_stream", {"lanes_per_row": r}))
+    for r in (32,):
+        v.append(("csr_stream", {"lanes_per_row": r, "stream_mode": 2}))
     for r in (8, 16):
         v.append(("csr_stream", {"lanes_per_row": r, "stream_mode": 1}))
     for i in (5, 7, 9, 11, 13):
