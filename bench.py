@@ -209,6 +209,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # one untimed exchange, checked: every rank must end up with the same padded x. If the in-place form (send buffer
+        # = own slice of the receive buffer) is not honoured by the backend, fall back to a separate send buffer.
+        import spmv_dist as D
+        x_expect = torch.from_numpy(D.scatter_x_padded(x_host, offsets, padded)).cuda()
+        dist.all_gather_into_tensor(x_full, x_send)
+        torch.cuda.synchronize()
+        if not torch.equal(x_full, x_expect):
+            x_full.zero_()
+            x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
+            x_send = x_loc.clone()
+            dist.all_gather_into_tensor(x_full, x_send)
+            torch.cuda.synchronize()
+            if not torch.equal(x_full, x_expect):
+                raise SystemExit("allgather(x) did not produce the expected padded vector")
+        del x_expect
     for _ in range(args.warmup):
         step()
     barrier()

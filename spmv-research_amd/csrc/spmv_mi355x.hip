@@ -610,7 +610,9 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 		}
 		case SPMV_MI355X_SELL_C_SIGMA:
 		{
-			int C = o.sell_c ? o.sell_c : 64;
+			// auto: one row per lane (C = 64, bit-exact) when there are enough slices to fill the chip several times over,
+			// else 16-row slices with 4 lanes per row (4x the wavefronts, 1/4 of the dependent chain) — profiles/sweep_r01.md
+			int C = o.sell_c ? o.sell_c : (lm >= 64L * 32768 ? 64 : 16);
 			if (C != 16 && C != 32 && C != 64)
 			{
 				set_error("sell_c must be 16, 32 or 64 (got %d)", C);
