@@ -11,7 +11,9 @@ A "step" is one y = A*x over the whole matrix with the matrix, x and y already r
           with the local-column part of the block, then the remote-column part accumulated into y. Total work is
           fixed as N grows -> "scaling": "strong".
 
-Default workload: 'nlpkkt240' (config 5 of BASELINE.json: 28.0 M rows, ~770 M non-zeros, fp64) — the largest
+Default workload: 'nlpkkt240' (config 5 of BASELINE.json: 28.0 M rows, ~770 M non-zeros, fp64), default format
+SELL-64-sigma with delta-compressed column indices (the engine's fastest format for it; `--format csr_stream` is the
+fastest kernel on plain CSR storage) — the largest
 single-GPU configuration, the one the multi-GPU target is quoted on, and far larger than the 256 MiB Infinity Cache,
 so the algorithmic GB/s below is real HBM traffic. The matrices are synthetic twins (no SuiteSparse file exists in
 the reference tree and there is no network): see spmv-research_amd/host/synthetic.cpp and DESIGN.md.
@@ -32,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spmv-research_amd", "python"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
-DEFAULT_FORMAT = {"nlpkkt240": "csr_stream", "cant": "csr_vector", "pwtk": "sell_c_sigma",
+DEFAULT_FORMAT = {"nlpkkt240": "sell_c_sigma", "cant": "csr_vector", "pwtk": "sell_c_sigma",
                   "scircuit": "csr_vector", "soc-LiveJournal1": "csr_merge"}
 DEFAULT_DTYPE = {"pwtk": "f32"}
 

@@ -73,7 +73,8 @@ typedef struct {
 	long col_begin;         /* optional column filter [col_begin,col_end) used for the local/remote split that lets    */
 	long col_end;           /*   the local part run while allgather(x) is in flight; 0,0 = no filter                   */
 	int  col_filter_mode;   /* 0 = keep all, 1 = keep columns inside [col_begin,col_end), 2 = keep columns outside     */
-	int  reserved1;
+	int  sell_delta;        /* SELL with 64-row slices: column indices stored as one base per step + 8/16-bit deltas per lane
+	                           where they fit (lossless, bit-identical results): 0 = auto (on when sell_c = 64), 1 = on, 2 = off */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */
@@ -120,7 +121,8 @@ void * spmv_mi355x_x_device(spmv_mi355x_matrix * A);
 void * spmv_mi355x_y_device(spmv_mi355x_matrix * A);
 
 /* ---- format introspection for parity tests (host copies of the converted arrays) -------------------------- */
-/* SELL-C-sigma layout: any out pointer may be NULL. Arrays are malloc'ed copies; free with spmv_mi355x_free(). */
+/* SELL-C-sigma layout: any out pointer may be NULL. Arrays are malloc'ed copies; free with spmv_mi355x_free().
+ * For delta-compressed handles the column array is DECODED back to the plain column-major layout. */
 int  spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma_out, long * num_slices_out,
 		long * nnz_ext_out, int64_t ** slice_ptr_out, int32_t ** col_out, double ** val_as_f64_out,
 		int32_t ** row_of_sorted_out);

@@ -56,6 +56,11 @@ struct spmv_mi355x_matrix {
 	long sell_sigma = 0, sell_slices = 0, sell_nnz_ext = 0;
 	int64_t * d_slice_ptr = nullptr;
 	int * d_row_of_sorted = nullptr;
+	bool sell_delta = false;               // delta-compressed column indices (C = 64 only)
+	int64_t * d_sell_desc = nullptr;
+	unsigned char * d_sell_idx = nullptr;
+	long sell_idx_bytes = 0;
+	long sell_mode_slices[3] = {0, 0, 0};  // slices stored with 8-bit / 16-bit / 32-bit indices
 	// COO
 	int coo_k = 0, coo_num_waves = 0;
 	int * d_rowind = nullptr;
@@ -99,7 +104,7 @@ static void
 free_all(spmv_mi355x_matrix * A)
 {
 	void * ptrs[] = {A->d_row_ptr, A->d_col, A->d_val, A->d_coords, A->d_carry_row, A->d_carry_val, A->d_slice_ptr,
-	                 A->d_row_of_sorted, A->d_rowind, A->d_x, A->d_y};
+	                 A->d_row_of_sorted, A->d_rowind, A->d_x, A->d_y, A->d_sell_desc, A->d_sell_idx};
 	for (void * p : ptrs)
 		if (p)
 			(void) hipFree(p);
@@ -266,6 +271,151 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 		return 1;
 	// (num_slices+1) offsets + padded entries + the row permutation (cf. sell_sorted.cpp:297)
 	A->mem_footprint = (double) (num_slices + 1) * sizeof(int64_t) + (double) nnz_ext * (A->vbytes + 4) + (double) m * 4;
+	return 0;
+}
+
+// SELL-64-sigma-delta build (layout: kernels_sell.hip). Same sigma-window sort and slice widths as build_sell with C = 64,
+// widths padded to a multiple of 4 steps; per slice the narrowest index encoding that holds every (step, lane) delta.
+static int
+build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va)
+{
+	const long m = A->m;
+	constexpr int C = 64;
+	const long sigma = A->sell_sigma;
+	const long num_slices = (m + C - 1) / C;
+	std::vector<int> row_of_sorted(std::max<long>(m, 1));
+	const long num_windows = (m + sigma - 1) / sigma;
+	#pragma omp parallel for schedule(dynamic, 4)
+	for (long w = 0; w < num_windows; w++)
+	{
+		long s = w * sigma, e = std::min(m, s + sigma);
+		int maxlen = 0;
+		for (long i = s; i < e; i++)
+			maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
+		std::vector<long> cnt((size_t) maxlen + 2, 0);
+		for (long i = s; i < e; i++)
+			cnt[maxlen - (rp[i + 1] - rp[i]) + 1]++;
+		for (int b = 0; b <= maxlen; b++)
+			cnt[b + 1] += cnt[b];
+		for (long i = s; i < e; i++)
+			row_of_sorted[s + cnt[maxlen - (rp[i + 1] - rp[i])]++] = (int) i;
+	}
+	// pass 1: width and mode of every slice
+	std::vector<int64_t> val_ptr((size_t) num_slices + 1, 0), idx_ptr((size_t) num_slices + 1, 0);
+	std::vector<unsigned char> mode((size_t) std::max<long>(num_slices, 1), 4);
+	#pragma omp parallel for schedule(dynamic, 64)
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		long width = 0;
+		const long i_e = std::min(m, (sl + 1) * C);
+		for (long i = sl * C; i < i_e; i++)
+		{
+			int o = row_of_sorted[i];
+			width = std::max<long>(width, rp[o + 1] - rp[o]);
+		}
+		width = (width + 3) / 4 * 4;
+		long maxdelta = 0;
+		for (long k = 0; k < width; k++)
+		{
+			int lo = 0x7fffffff, hi = -1;
+			for (long i = sl * C; i < i_e; i++)
+			{
+				int o = row_of_sorted[i];
+				if (k < rp[o + 1] - rp[o])
+				{
+					int c = ci[rp[o] + k];
+					lo = std::min(lo, c);
+					hi = std::max(hi, c);
+				}
+			}
+			if (hi >= 0)
+				maxdelta = std::max<long>(maxdelta, (long) hi - lo);
+		}
+		const int md = maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		mode[sl] = (unsigned char) md;
+		val_ptr[sl + 1] = width * C;
+		idx_ptr[sl + 1] = (width / 4) * (md == 1 ? 272 : md == 2 ? 528 : 1024);
+	}
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		val_ptr[sl + 1] += val_ptr[sl];
+		idx_ptr[sl + 1] += idx_ptr[sl];
+		A->sell_mode_slices[mode[sl] == 1 ? 0 : mode[sl] == 2 ? 1 : 2]++;
+	}
+	const int64_t nnz_ext = val_ptr[num_slices];
+	const int64_t idx_bytes = idx_ptr[num_slices];
+	std::vector<double> val((size_t) std::max<int64_t>(nnz_ext, 1));
+	std::vector<unsigned char> idx((size_t) std::max<int64_t>(idx_bytes, 16) + 1024, 0);
+	std::vector<int64_t> desc(2 * ((size_t) num_slices + 1), 0);
+	#pragma omp parallel for schedule(dynamic, 64)
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		const int64_t vb = val_ptr[sl];
+		const long width = (val_ptr[sl + 1] - vb) / C;
+		const int md = mode[sl];
+		unsigned char * ib = idx.data() + idx_ptr[sl];
+		desc[2 * sl] = vb;
+		desc[2 * sl + 1] = idx_ptr[sl] | md;
+		const long i_e = std::min(m, (sl + 1) * C);
+		for (long k = 0; k < width; k++)
+		{
+			int base = 0x7fffffff;
+			for (long i = sl * C; i < i_e; i++)
+			{
+				int o = row_of_sorted[i];
+				if (k < rp[o + 1] - rp[o])
+					base = std::min(base, ci[rp[o] + k]);
+			}
+			if (base == 0x7fffffff)
+				base = 0;                              // a step that is padding for every lane
+			const long g = k / 4, u = k % 4;
+			const long gbytes = md == 1 ? 272 : md == 2 ? 528 : 1024;
+			unsigned char * gp = ib + g * gbytes;
+			if (md != 4)
+				reinterpret_cast<int *>(gp)[u] = base;
+			for (int r = 0; r < C; r++)
+			{
+				const long i = sl * C + r;
+				double v = 0.0;
+				int c = base;                              // padding: value 0 times a column some lane really uses
+				if (i < m)
+				{
+					int o = row_of_sorted[i];
+					if (k < rp[o + 1] - rp[o])
+					{
+						c = ci[rp[o] + k];
+						v = va[rp[o] + k];
+					}
+				}
+				val[vb + k * C + r] = v;
+				const unsigned d = (unsigned) (c - base);
+				if (md == 1)
+					gp[16 + r * 4 + u] = (unsigned char) d;
+				else if (md == 2)
+					reinterpret_cast<unsigned short *>(gp + 16)[r * 4 + u] = (unsigned short) d;
+				else
+					reinterpret_cast<int *>(gp)[u * C + r] = c;
+			}
+		}
+	}
+	desc[2 * num_slices] = nnz_ext;
+	desc[2 * num_slices + 1] = idx_bytes | 4;
+	A->sell_slices = num_slices;
+	A->sell_nnz_ext = nnz_ext;
+	A->sell_idx_bytes = idx_bytes;
+	A->cfg.map = xcd_map_balanced(val_ptr.data(), num_slices, sell_slices_per_tile(),
+			resolve_remap(A->remap, (num_slices + sell_slices_per_tile() - 1) / sell_slices_per_tile()));
+	if (dev_alloc(&A->d_sell_desc, desc.size()))
+		return 1;
+	HIP_TRY(hipMemcpy(A->d_sell_desc, desc.data(), desc.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+	if (dev_alloc(&A->d_sell_idx, idx.size()))
+		return 1;
+	HIP_TRY(hipMemcpy(A->d_sell_idx, idx.data(), idx.size(), hipMemcpyHostToDevice));
+	if (upload_values(A, val.data(), (size_t) nnz_ext, &A->d_val))
+		return 1;
+	if (upload_ints(row_of_sorted.data(), (size_t) m, &A->d_row_of_sorted))
+		return 1;
+	A->mem_footprint = (double) (num_slices + 1) * 16 + (double) nnz_ext * A->vbytes + (double) idx_bytes + (double) m * 4;
 	return 0;
 }
 
@@ -628,9 +778,16 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 			}
 			A->sell_c = C;
 			A->sell_sigma = sigma;
-			rc = build_sell(A, rp, ci, va);
-			snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELL_%d_%ld_%s", C, sigma, pf);
-			snprintf(A->kernel_name, sizeof(A->kernel_name), "sell_kernel");
+			A->sell_delta = (C == 64) && (o.sell_delta != 2);      // 0 = auto (on for 64-row slices), 1 = on, 2 = off
+			if (o.sell_delta == 1 && C != 64)
+			{
+				set_error("sell_delta needs sell_c = 64 (one lane per row)");
+				rc = 1;
+				break;
+			}
+			rc = A->sell_delta ? build_sell_delta(A, rp, ci, va) : build_sell(A, rp, ci, va);
+			snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELL%s_%d_%ld_%s", A->sell_delta ? "D" : "", C, sigma, pf);
+			snprintf(A->kernel_name, sizeof(A->kernel_name), A->sell_delta ? "sell_delta_kernel" : "sell_kernel");
 			break;
 		}
 		case SPMV_MI355X_COO:
@@ -718,7 +875,10 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 					A->merge_num_tiles, A->d_coords, A->d_carry_row, A->d_carry_val, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_SELL_C_SIGMA:
-			rc = launch_sell(A->f32, A->sell_c, A->d_slice_ptr, A->d_col, A->d_val, A->d_row_of_sorted, x, y, (int) A->m,
+			rc = A->sell_delta
+			     ? launch_sell_delta(A->f32, A->d_sell_desc, A->d_sell_idx, A->d_val, A->d_row_of_sorted, x, y, (int) A->m,
+					(int) A->sell_slices, cfg, st, &grid)
+			     : launch_sell(A->f32, A->sell_c, A->d_slice_ptr, A->d_col, A->d_val, A->d_row_of_sorted, x, y, (int) A->m,
 					(int) A->sell_slices, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_COO:
@@ -842,16 +1002,58 @@ spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma
 	if (sigma_out) *sigma_out = A->sell_sigma;
 	if (num_slices_out) *num_slices_out = A->sell_slices;
 	if (nnz_ext_out) *nnz_ext_out = A->sell_nnz_ext;
+	std::vector<int64_t> h_desc;
+	std::vector<unsigned char> h_idx;
+	if (A->sell_delta)
+	{
+		h_desc.resize(2 * ((size_t) A->sell_slices + 1));
+		HIP_TRY(hipMemcpy(h_desc.data(), A->d_sell_desc, h_desc.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+		h_idx.resize((size_t) std::max<long>(A->sell_idx_bytes, 1));
+		HIP_TRY(hipMemcpy(h_idx.data(), A->d_sell_idx, (size_t) A->sell_idx_bytes, hipMemcpyDeviceToHost));
+	}
 	if (slice_ptr_out)
 	{
 		*slice_ptr_out = (int64_t *) malloc(((size_t) A->sell_slices + 1) * sizeof(int64_t));
-		HIP_TRY(hipMemcpy(*slice_ptr_out, A->d_slice_ptr, ((size_t) A->sell_slices + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+		if (A->sell_delta)
+			for (long sl = 0; sl <= A->sell_slices; sl++)
+				(*slice_ptr_out)[sl] = h_desc[2 * sl];
+		else
+			HIP_TRY(hipMemcpy(*slice_ptr_out, A->d_slice_ptr, ((size_t) A->sell_slices + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
 	}
 	size_t ne = (size_t) std::max<long>(A->sell_nnz_ext, 1);
 	if (col_out)
 	{
 		*col_out = (int32_t *) malloc(ne * sizeof(int32_t));
-		HIP_TRY(hipMemcpy(*col_out, A->d_col, (size_t) A->sell_nnz_ext * sizeof(int32_t), hipMemcpyDeviceToHost));
+		if (A->sell_delta)
+		{
+			// decode the compressed indices back to the plain column-major layout
+			for (long sl = 0; sl < A->sell_slices; sl++)
+			{
+				const int64_t vb = h_desc[2 * sl];
+				const long width = (h_desc[2 * sl + 2] - vb) / 64;
+				const int md = (int) (h_desc[2 * sl + 1] & 7);
+				const unsigned char * ib = h_idx.data() + (h_desc[2 * sl + 1] & ~(int64_t) 15);
+				const long gbytes = md == 1 ? 272 : md == 2 ? 528 : 1024;
+				for (long k = 0; k < width; k++)
+				{
+					const unsigned char * gp = ib + (k / 4) * gbytes;
+					const long u = k % 4;
+					for (int r = 0; r < 64; r++)
+					{
+						int c;
+						if (md == 1)
+							c = reinterpret_cast<const int *>(gp)[u] + gp[16 + r * 4 + u];
+						else if (md == 2)
+							c = reinterpret_cast<const int *>(gp)[u] + reinterpret_cast<const unsigned short *>(gp + 16)[r * 4 + u];
+						else
+							c = reinterpret_cast<const int *>(gp)[u * 64 + r];
+						(*col_out)[vb + k * 64 + r] = c;
+					}
+				}
+			}
+		}
+		else
+			HIP_TRY(hipMemcpy(*col_out, A->d_col, (size_t) A->sell_nnz_ext * sizeof(int32_t), hipMemcpyDeviceToHost));
 	}
 	if (val_out)
 	{

@@ -41,8 +41,10 @@ VARIANTS = [
     ("csr_merge", {}, False),
     ("csr_merge", {"merge_items": 5}, False),
     ("csr_merge", {"merge_items": 13}, False),
-    ("sell_c_sigma", {"sell_c": 64}, True),
+    ("sell_c_sigma", {"sell_c": 64}, True),                              # delta-compressed indices (auto for C = 64)
     ("sell_c_sigma", {"sell_c": 64, "sell_sigma": 64}, True),
+    ("sell_c_sigma", {"sell_c": 64, "sell_delta": 2}, True),             # plain int32 indices
+    ("sell_c_sigma", {"sell_c": 64, "sell_delta": 1, "sell_sigma": 1024}, True),
     ("sell_c_sigma", {"sell_c": 32, "sell_sigma": 256}, False),
     ("sell_c_sigma", {"sell_c": 16, "sell_sigma": 16384}, False),
     ("coo", {}, False),
@@ -214,11 +216,31 @@ def test_formats_report_footprint(eng):
     A = eng.Matrix(rp, ci, a, m, n, "coo")
     assert A.mem_footprint == nnz * 16          # mkl_coo.cpp:65
     A.close()
-    A = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", np.float32, sell_c=64)
+    A = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", np.float32, sell_c=64, sell_delta=2)
     lay = A.sell_layout()
     assert A.mem_footprint == (lay["num_slices"] + 1) * 8 + lay["nnz_ext"] * 8 + m * 4
     assert lay["nnz_ext"] >= nnz and sorted(lay["row_of_sorted"].tolist()) == list(range(m))
+    plain_fp = A.mem_footprint
     A.close()
+    # delta-compressed indices: same rows / values / (decoded) columns, smaller footprint on a banded matrix
+    B = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", np.float32, sell_c=64, sell_delta=1)
+    layd = B.sell_layout()
+    assert B.mem_footprint < plain_fp
+    np.testing.assert_array_equal(layd["row_of_sorted"], lay["row_of_sorted"])
+    # widths are padded to 4 steps in the compressed layout: compare entry by entry through the slice pointers
+    for s in range(lay["num_slices"]):
+        w0 = (lay["slice_ptr"][s + 1] - lay["slice_ptr"][s]) // 64
+        w1 = (layd["slice_ptr"][s + 1] - layd["slice_ptr"][s]) // 64
+        assert w1 >= w0 and w1 - w0 < 4
+        c0 = lay["col"][lay["slice_ptr"][s]:lay["slice_ptr"][s + 1]].reshape(w0, 64)
+        v0 = lay["val"][lay["slice_ptr"][s]:lay["slice_ptr"][s + 1]].reshape(w0, 64)
+        c1 = layd["col"][layd["slice_ptr"][s]:layd["slice_ptr"][s + 1]].reshape(w1, 64)
+        v1 = layd["val"][layd["slice_ptr"][s]:layd["slice_ptr"][s + 1]].reshape(w1, 64)
+        np.testing.assert_array_equal(v1[:w0], v0)
+        real = v0 != 0
+        np.testing.assert_array_equal(c1[:w0][real], c0[real])      # padding columns may differ, real entries may not
+        assert np.all(v1[w0:] == 0)
+    B.close()
 
 
 def test_create_rejects_bad_input(eng):

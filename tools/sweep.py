@@ -27,6 +27,7 @@ def variants(dts):
         v.append(("csr_merge", {"merge_items": i}))
     for c in (16, 32, 64):
         v.append(("sell_c_sigma", {"sell_c": c}))
+    v.append(("sell_c_sigma", {"sell_c": 64, "sell_delta": 2}))
     for k in (2, 4, 8):
         v.append(("coo", {"merge_items": k}))
     return v
