@@ -57,7 +57,7 @@ typedef struct {
 	int  device;            /* HIP device ordinal; -1 = the current device                                        */
 	int  lanes_per_row;     /* CSR_VECTOR: 2,4,8,16,32,64; 0 = chosen from mean nnz/row                            */
 	                        /* CSR_STREAM: the same field holds ROWS PER WAVEFRONT (4,8,16,32,64); 0 = auto          */
-	int  block_threads;     /* threads per workgroup (multiple of 64); 0 = 256                                     */
+	int  sell_split;        /* SELL delta format: wavefronts sharing one 64-row slice (1, 2 or 4); 0 = auto by slice count */
 	int  sell_c;            /* SELL: rows per slice (16, 32 or 64); 0 = 64 (one wavefront = one slice)             */
 	int  sell_sigma;        /* SELL: sort window in rows (multiple of sell_c); 0 = 16384 (sell_c_s.cpp:58-60)      */
 	int  merge_items;       /* MERGE: merge items per thread (5,7,9,11,13); COO: entries per lane (2,4,8); 0 = default */

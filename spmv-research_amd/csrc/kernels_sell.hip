@@ -183,17 +183,19 @@ sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * 
 	s = fma_t<T>(v3, x3, s);
 }
 
+// groups g0, g0+gs, g0+2gs, ... of one slice (gs = 1: the whole slice, in order)
 template <typename T, int MODE, bool NT>
 __device__ __forceinline__ T
-sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int groups, int lane, const T * __restrict__ x)
+sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int groups, int lane, const T * __restrict__ x,
+		int g0 = 0, int gs = 1)
 {
 	constexpr int GB = MODE == 1 ? 272 : MODE == 2 ? 528 : 1024;     // bytes of one index group
 	T s = 0;
-	int g = 0;
-	for (; g + 1 < groups; g += 2)          // 8 steps in flight per trip
+	int g = g0;
+	for (; g + gs < groups; g += 2 * gs)    // 8 steps in flight per trip
 	{
 		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s);
-		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + 1) * GB, vp + (size_t) (g + 1) * 4 * WAVE, lane, x, s);
+		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + gs) * GB, vp + (size_t) (g + gs) * 4 * WAVE, lane, x, s);
 	}
 	if (g < groups)
 		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s);
@@ -236,9 +238,61 @@ sell_delta_kernel(const int64_t * __restrict__ desc, const unsigned char * __res
 	}
 }
 
+// Small matrices (a few thousand slices) cannot fill 256 CUs with one wave per slice: S waves share a slice, wave w takes
+// the index groups w, w+S, ..., the S partial sums of a row meet in LDS and are added in wave order (deterministic;
+// no longer the sequential order, so parity is to tolerance). One workgroup = 4/S slices.
+template <typename T, int S, bool NT>
+__global__ __launch_bounds__(SELL_BLOCK) void
+sell_delta_split_kernel(const int64_t * __restrict__ desc, const unsigned char * __restrict__ idx, const T * __restrict__ val,
+		const int * __restrict__ row_of_sorted, const T * __restrict__ x, T * __restrict__ y,
+		int m, int num_slices, int beta, XcdMap map)
+{
+	constexpr int SPB = SELL_WAVES / S;      // slices per workgroup
+	__shared__ T s_part[SELL_WAVES][WAVE];
+	unsigned tile = xcd_tile(blockIdx.x, map);
+	if (tile == NO_TILE)
+		return;
+	const int lane = threadIdx.x % WAVE;
+	const int wave = threadIdx.x / WAVE;
+	const int w = wave % S;
+	const int slice = __builtin_amdgcn_readfirstlane((int) (tile * SPB + wave / S));
+	T s = 0;
+	if (slice < num_slices)
+	{
+		const int64_t v_off = desc[2 * slice];
+		const int64_t i_word = desc[2 * slice + 1];
+		const int64_t v_next = desc[2 * slice + 2];
+		const int mode = (int) (i_word & 7);
+		const unsigned char * ip = idx + (i_word & ~(int64_t) 15);
+		const T * vp = val + v_off + lane;
+		const int groups = (int) ((v_next - v_off) / (4 * WAVE));
+		if (mode == 1)
+			s = sell_delta_slice<T, 1, NT>(ip, vp, groups, lane, x, w, S);
+		else if (mode == 2)
+			s = sell_delta_slice<T, 2, NT>(ip, vp, groups, lane, x, w, S);
+		else
+			s = sell_delta_slice<T, 4, NT>(ip, vp, groups, lane, x, w, S);
+	}
+	s_part[wave][lane] = s;
+	__syncthreads();
+	if (w == 0 && slice < num_slices)
+	{
+		T t = s_part[wave][lane];
+		#pragma unroll
+		for (int u = 1; u < S; u++)
+			t += s_part[wave + u][lane];
+		const long sorted_row = (long) slice * WAVE + lane;
+		if (sorted_row < m)
+		{
+			T * yp = y + row_of_sorted[sorted_row];
+			*yp = beta ? *yp + t : t;
+		}
+	}
+}
+
 template <typename T>
 static int
-sell_delta_launch(const int64_t * desc, const unsigned char * idx, const void * val, const int * row_of_sorted, const void * x, void * y,
+sell_delta_launch(int S, const int64_t * desc, const unsigned char * idx, const void * val, const int * row_of_sorted, const void * x, void * y,
 		int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
 	unsigned grid = xcd_grid(cfg.map);
@@ -246,22 +300,39 @@ sell_delta_launch(const int64_t * desc, const unsigned char * idx, const void * 
 		*grid_out = grid;
 	if (grid == 0)
 		return 0;
-	if (cfg.nt)
-		hipLaunchKernelGGL((sell_delta_kernel<T, true>), dim3(grid), dim3(SELL_BLOCK), 0, stream, desc, idx, (const T *) val,
-				row_of_sorted, (const T *) x, (T *) y, m, num_slices, cfg.beta, cfg.map);
+	#define SELLD_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(SELL_BLOCK), 0, stream, desc, idx, (const T *) val, \
+			row_of_sorted, (const T *) x, (T *) y, m, num_slices, cfg.beta, cfg.map)
+	if (S == 1)
+	{
+		if (cfg.nt) SELLD_LAUNCH((sell_delta_kernel<T, true>));
+		else        SELLD_LAUNCH((sell_delta_kernel<T, false>));
+	}
+	else if (S == 2)
+	{
+		if (cfg.nt) SELLD_LAUNCH((sell_delta_split_kernel<T, 2, true>));
+		else        SELLD_LAUNCH((sell_delta_split_kernel<T, 2, false>));
+	}
+	else if (S == 4)
+	{
+		if (cfg.nt) SELLD_LAUNCH((sell_delta_split_kernel<T, 4, true>));
+		else        SELLD_LAUNCH((sell_delta_split_kernel<T, 4, false>));
+	}
 	else
-		hipLaunchKernelGGL((sell_delta_kernel<T, false>), dim3(grid), dim3(SELL_BLOCK), 0, stream, desc, idx, (const T *) val,
-				row_of_sorted, (const T *) x, (T *) y, m, num_slices, cfg.beta, cfg.map);
+	{
+		set_error("sell_delta: waves per slice must be 1, 2 or 4 (got %d)", S);
+		return 1;
+	}
+	#undef SELLD_LAUNCH
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
 
 int
-launch_sell_delta(bool f32, const int64_t * desc, const unsigned char * idx, const void * val, const int * row_of_sorted,
+launch_sell_delta(bool f32, int waves_per_slice, const int64_t * desc, const unsigned char * idx, const void * val, const int * row_of_sorted,
 		const void * x, void * y, int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
-	return f32 ? sell_delta_launch<float>(desc, idx, val, row_of_sorted, x, y, m, num_slices, cfg, stream, grid_out)
-	           : sell_delta_launch<double>(desc, idx, val, row_of_sorted, x, y, m, num_slices, cfg, stream, grid_out);
+	return f32 ? sell_delta_launch<float>(waves_per_slice, desc, idx, val, row_of_sorted, x, y, m, num_slices, cfg, stream, grid_out)
+	           : sell_delta_launch<double>(waves_per_slice, desc, idx, val, row_of_sorted, x, y, m, num_slices, cfg, stream, grid_out);
 }
 
 template <typename T, int C>

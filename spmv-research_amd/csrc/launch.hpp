@@ -53,7 +53,7 @@ int launch_sell(bool f32, int C, const int64_t * slice_ptr, const int * col, con
 		const void * x, void * y, int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
 // SELL-64-sigma with delta-compressed column indices (desc: 2 int64 per slice + terminator, idx: byte stream)
-int launch_sell_delta(bool f32, const int64_t * desc, const unsigned char * idx, const void * val, const int * row_of_sorted,
+int launch_sell_delta(bool f32, int waves_per_slice, const int64_t * desc, const unsigned char * idx, const void * val, const int * row_of_sorted,
 		const void * x, void * y, int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
 // ---- COO (kernels_coo.hip)

@@ -57,6 +57,7 @@ struct spmv_mi355x_matrix {
 	int64_t * d_slice_ptr = nullptr;
 	int * d_row_of_sorted = nullptr;
 	bool sell_delta = false;               // delta-compressed column indices (C = 64 only)
+	int sell_split = 1;                    // waves sharing one slice (delta format): 1, 2 or 4
 	int64_t * d_sell_desc = nullptr;
 	unsigned char * d_sell_idx = nullptr;
 	long sell_idx_bytes = 0;
@@ -403,8 +404,10 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 	A->sell_slices = num_slices;
 	A->sell_nnz_ext = nnz_ext;
 	A->sell_idx_bytes = idx_bytes;
-	A->cfg.map = xcd_map_balanced(val_ptr.data(), num_slices, sell_slices_per_tile(),
-			resolve_remap(A->remap, (num_slices + sell_slices_per_tile() - 1) / sell_slices_per_tile()));
+	{
+		const long spt = sell_slices_per_tile() / A->sell_split;       // slices per workgroup
+		A->cfg.map = xcd_map_balanced(val_ptr.data(), num_slices, spt, resolve_remap(A->remap, (num_slices + spt - 1) / spt));
+	}
 	if (dev_alloc(&A->d_sell_desc, desc.size()))
 		return 1;
 	HIP_TRY(hipMemcpy(A->d_sell_desc, desc.data(), desc.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -762,7 +765,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 		{
 			// auto: one row per lane (C = 64, bit-exact) when there are enough slices to fill the chip several times over,
 			// else 16-row slices with 4 lanes per row (4x the wavefronts, 1/4 of the dependent chain) — profiles/sweep_r01.md
-			int C = o.sell_c ? o.sell_c : (lm >= 64L * 32768 ? 64 : 16);
+			int C = o.sell_c ? o.sell_c : 64;
 			if (C != 16 && C != 32 && C != 64)
 			{
 				set_error("sell_c must be 16, 32 or 64 (got %d)", C);
@@ -779,6 +782,18 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 			A->sell_c = C;
 			A->sell_sigma = sigma;
 			A->sell_delta = (C == 64) && (o.sell_delta != 2);      // 0 = auto (on for 64-row slices), 1 = on, 2 = off
+			{
+				// waves per slice: enough wavefronts to occupy 256 CUs several times over
+				const long slices = (lm + 63) / 64;
+				int S = o.sell_split ? o.sell_split : (slices >= 16384 ? 1 : slices >= 8192 ? 2 : 4);
+				if (S != 1 && S != 2 && S != 4)
+				{
+					set_error("sell_split must be 1, 2 or 4 (got %d)", S);
+					rc = 1;
+					break;
+				}
+				A->sell_split = A->sell_delta ? S : 1;
+			}
 			if (o.sell_delta == 1 && C != 64)
 			{
 				set_error("sell_delta needs sell_c = 64 (one lane per row)");
@@ -786,7 +801,10 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 				break;
 			}
 			rc = A->sell_delta ? build_sell_delta(A, rp, ci, va) : build_sell(A, rp, ci, va);
-			snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELL%s_%d_%ld_%s", A->sell_delta ? "D" : "", C, sigma, pf);
+			if (A->sell_delta && A->sell_split > 1)
+				snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELLD_%d_%ld_w%d_%s", C, sigma, A->sell_split, pf);
+			else
+				snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELL%s_%d_%ld_%s", A->sell_delta ? "D" : "", C, sigma, pf);
 			snprintf(A->kernel_name, sizeof(A->kernel_name), A->sell_delta ? "sell_delta_kernel" : "sell_kernel");
 			break;
 		}
@@ -876,7 +894,7 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 			break;
 		case SPMV_MI355X_SELL_C_SIGMA:
 			rc = A->sell_delta
-			     ? launch_sell_delta(A->f32, A->d_sell_desc, A->d_sell_idx, A->d_val, A->d_row_of_sorted, x, y, (int) A->m,
+			     ? launch_sell_delta(A->f32, A->sell_split, A->d_sell_desc, A->d_sell_idx, A->d_val, A->d_row_of_sorted, x, y, (int) A->m,
 					(int) A->sell_slices, cfg, st, &grid)
 			     : launch_sell(A->f32, A->sell_c, A->d_slice_ptr, A->d_col, A->d_val, A->d_row_of_sorted, x, y, (int) A->m,
 					(int) A->sell_slices, cfg, st, &grid);

@@ -21,7 +21,7 @@ F64, F32 = 0, 1
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("lanes_per_row", C.c_int),
-                ("block_threads", C.c_int), ("sell_c", C.c_int), ("sell_sigma", C.c_int),
+                ("sell_split", C.c_int), ("sell_c", C.c_int), ("sell_sigma", C.c_int),
                 ("merge_items", C.c_int), ("xcd_remap", C.c_int), ("nontemporal", C.c_int),
                 ("stream_mode", C.c_int),
                 ("row_begin", C.c_long), ("row_end", C.c_long), ("col_begin", C.c_long), ("col_end", C.c_long),

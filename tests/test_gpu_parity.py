@@ -41,10 +41,13 @@ VARIANTS = [
     ("csr_merge", {}, False),
     ("csr_merge", {"merge_items": 5}, False),
     ("csr_merge", {"merge_items": 13}, False),
-    ("sell_c_sigma", {"sell_c": 64}, True),                              # delta-compressed indices (auto for C = 64)
-    ("sell_c_sigma", {"sell_c": 64, "sell_sigma": 64}, True),
+    ("sell_c_sigma", {"sell_c": 64, "sell_split": 1}, True),             # delta-compressed indices, one wave per slice
+    ("sell_c_sigma", {"sell_c": 64, "sell_sigma": 64, "sell_split": 1}, True),
+    ("sell_c_sigma", {}, False),                                           # auto: C = 64, delta, waves per slice by size
+    ("sell_c_sigma", {"sell_split": 2}, False),
+    ("sell_c_sigma", {"sell_split": 4, "sell_sigma": 128}, False),
     ("sell_c_sigma", {"sell_c": 64, "sell_delta": 2}, True),             # plain int32 indices
-    ("sell_c_sigma", {"sell_c": 64, "sell_delta": 1, "sell_sigma": 1024}, True),
+    ("sell_c_sigma", {"sell_c": 64, "sell_delta": 1, "sell_sigma": 1024, "sell_split": 1}, True),
     ("sell_c_sigma", {"sell_c": 32, "sell_sigma": 256}, False),
     ("sell_c_sigma", {"sell_c": 16, "sell_sigma": 16384}, False),
     ("coo", {}, False),

@@ -28,6 +28,8 @@ def variants(dts):
     for c in (16, 32, 64):
         v.append(("sell_c_sigma", {"sell_c": c}))
     v.append(("sell_c_sigma", {"sell_c": 64, "sell_delta": 2}))
+    for sp in (1, 2, 4):
+        v.append(("sell_c_sigma", {"sell_c": 64, "sell_split": sp}))
     for k in (2, 4, 8):
         v.append(("coo", {"merge_items": k}))
     return v
