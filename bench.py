@@ -55,7 +55,10 @@ def parse():
     ap.add_argument("--merge-items", type=int, default=0)
     ap.add_argument("--nontemporal", type=int, default=0)
     ap.add_argument("--xcd-remap", type=int, default=0)
-    ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap allgather(x) with the local-column part")
+    ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap the x exchange with the local-column part")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "p2p"],
+                    help="N>1: RCCL allgather of the padded x slices, or grouped send/recv of only the sub-ranges each row "
+                         "block reads (same result); auto = time both in the warm-up and keep the faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -91,6 +94,11 @@ def load_traffic(workload, fmt, dtype):
 
 def main():
     args = parse()
+    # torch.distributed.run pins OMP_NUM_THREADS=1 for its children; the host-side generation / format conversion is
+    # OpenMP code, so give each rank its share of the cores back before any OpenMP runtime starts
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
+        share = max(1, min(16, len(os.sched_getaffinity(0)) // int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))))
+        os.environ["OMP_NUM_THREADS"] = str(share)
     import torch
     import spmv_host as H
     import spmv_mi355x as E
@@ -194,16 +202,25 @@ def main():
     compute = torch.cuda.current_stream()
     sp = compute.cuda_stream
 
+    use_p2p = False
+    exch = None
+
     def step():
         if world == 1:
             mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
-        elif args.overlap:
-            work = dist.all_gather_into_tensor(x_full, x_send, async_op=True)
+            return
+        if use_p2p:
+            reqs = exch.start()
+        else:
+            reqs = [dist.all_gather_into_tensor(x_full, x_send, async_op=True)]
+        if args.overlap:
             mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)      # local columns: only the own slice of x
-            work.wait()
+            for r in reqs:
+                r.wait()
             mats[1].spmv_device(x_full.data_ptr(), y.data_ptr(), 1, sp)      # remote columns, y += ...
         else:
-            dist.all_gather_into_tensor(x_full, x_send)
+            for r in reqs:
+                r.wait()
             mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
 
     def barrier():
@@ -211,6 +228,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange_info = None
     if world > 1:
         # one untimed exchange, checked: every rank must end up with the same padded x. If the in-place form (send buffer
         # = own slice of the receive buffer) is not honoured by the backend, fall back to a separate send buffer.
@@ -226,6 +244,58 @@ def main():
             torch.cuda.synchronize()
             if not torch.equal(x_full, x_expect):
                 raise SystemExit("allgather(x) did not produce the expected padded vector")
+        exchange_info = {"chosen": "allgather"}
+        if args.exchange != "allgather":
+            # trimmed exchange: validated against the same expectation on the ranges it promises to deliver; every rank
+            # must agree that it works, otherwise all stay with the allgather
+            ok = 1
+            try:
+                lo, hi = D.needed_ranges(blk["col_idx"], padded, world)
+                exch = D.TrimmedExchange(dist, x_full, padded, rank, world, lo, hi)
+                x_full.zero_()
+                x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
+                for r in exch.start():
+                    r.wait()
+                torch.cuda.synchronize()
+                for q in range(world):
+                    a, b = q * padded + int(lo[q]), q * padded + int(hi[q])
+                    if q != rank and b > a and not torch.equal(x_full[a:b], x_expect[a:b]):
+                        ok = 0
+            except Exception as e:                      # e.g. a rehearsal backend without device send/recv
+                ok = 0
+                exchange_info["p2p_error"] = repr(e)[:200]
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchange_info["p2p_recv_fraction_of_allgather"] = round(exch.recv_elems / float((world - 1) * padded), 4)
+                if args.exchange == "p2p":
+                    use_p2p = True
+                else:
+                    # auto: a few untimed steps of each, max over ranks, keep the faster
+                    t_each = {}
+                    for name, flagv in (("allgather", False), ("p2p", True)):
+                        use_p2p = flagv
+                        for _ in range(3):
+                            step()
+                        if dist is not None:
+                            dist.barrier()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(10):
+                            step()
+                        torch.cuda.synchronize()
+                        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        t_each[name] = float(tt.item()) / 10 * 1e3
+                    use_p2p = t_each["p2p"] < t_each["allgather"]
+                    exchange_info.update({"allgather_ms": round(t_each["allgather"], 4), "p2p_ms": round(t_each["p2p"], 4)})
+                exchange_info["chosen"] = "p2p" if use_p2p else "allgather"
+            if not use_p2p:
+                # leave x_full complete for the allgather path
+                x_full.zero_()
+                x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
+                dist.all_gather_into_tensor(x_full, x_send)
+                torch.cuda.synchronize()
         del x_expect
     for _ in range(args.warmup):
         step()
@@ -292,7 +362,8 @@ def main():
         "config": {"workload": f"{workload} (synthetic twin)" + ("" if args.scale == 1.0 else f" scale={args.scale}"),
                    "format": mats[0].format_name, "rows": int(m), "cols": int(n), "nnz": int(nnz_total),
                    "parallelism": "single GPU" if world == 1 else
-                   f"row-partitioned x{world}, RCCL allgather(x) {'overlapped with local columns' if args.overlap else 'then SpMV'}"},
+                   f"row-partitioned x{world}, RCCL {'send/recv of the needed x ranges' if use_p2p else 'allgather(x)'} "
+                   f"{'overlapped with local columns' if args.overlap else 'then SpMV'}"},
         "hbm_gbps_algorithmic": round(B_alg / (ms_per_step * 1e-3) / 1e9, 2),
         "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 2),
         "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -301,6 +372,7 @@ def main():
                      "kernel": ki["name"], "kernel_ms": round(kernel_ms, 6),
                      "algorithmic_bytes_per_launch": int(B_alg_local)},
         "check_max_err_over_abs_row": max_rel,
+        "exchange": exchange_info,
         "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t_conv, 2)},
     }
 

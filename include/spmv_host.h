@@ -87,6 +87,10 @@ int  spmv_host_gen_kkt_block(long N, unsigned long seed, long row_begin, long ro
  * p*padded + (c - offsets[p]); offsets has parts+1 entries. In place. */
 int  spmv_host_remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, long padded);
 
+/* For columns already in the padded layout: the sub-range [lo[q],hi[q]) of each part's slice that is referenced at all
+ * (hi[q] <= lo[q]: none). Used to trim the x exchange to what a row block really reads. */
+int  spmv_host_column_ranges(const int32_t * col_idx, long nnz, long padded, long parts, long * lo, long * hi);
+
 /* Structural features the reference uses to describe a matrix (lib/storage_formats/csr_util/csr_util_gen.c:437-447,
  * 596-695,961): out[0..6] = avg nnz/row, std nnz/row, avg bandwidth scaled by n, skew = (max-avg)/avg,
  * avg_num_neighbours (window 1), cross_row_similarity (window 1), max nnz/row. */

@@ -24,6 +24,7 @@ int gen_twin(long nr_rows, long nr_cols, double avg, double std, double bw_scale
 int gen_kkt(long N, unsigned long seed, spmv_host_csr * out);
 int gen_kkt_row_ptr(long N, int32_t * row_ptr, long * m_out, long * nnz_out);
 int gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out);
+int column_ranges(const int32_t * col_idx, long nnz, long padded, long parts, long * lo, long * hi);
 int remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, long padded);
 int csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out7);
 

@@ -136,6 +136,12 @@ spmv_host_remap_columns(int32_t * col_idx, long nnz, const long * offsets, long 
 	return remap_columns(col_idx, nnz, offsets, parts, padded);
 }
 
+int
+spmv_host_column_ranges(const int32_t * col_idx, long nnz, long padded, long parts, long * lo, long * hi)
+{
+	return column_ranges(col_idx, nnz, padded, parts, lo, hi);
+}
+
 // Twin strings of benchmark_code/BENCH/config.sh:402,413,430,449 (seed 14 in every one).
 int
 spmv_host_gen_named(const char * name, double scale, spmv_host_csr * out)

@@ -435,4 +435,47 @@ remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, lon
 	return 0;
 }
 
+// For a block whose columns live in the padded slice layout: the sub-range [lo[q], hi[q]) of every part q's slice that
+// the block references at all (hi <= lo: nothing). Lets a rank fetch only those ranges instead of whole slices.
+int
+column_ranges(const int32_t * col_idx, long nnz, long padded, long parts, long * lo, long * hi)
+{
+	for (long q = 0; q < parts; q++)
+	{
+		lo[q] = padded;
+		hi[q] = 0;
+	}
+	int bad = 0;
+	#pragma omp parallel
+	{
+		std::vector<long> tlo((size_t) parts, padded), thi((size_t) parts, 0);
+		#pragma omp for nowait
+		for (long j = 0; j < nnz; j++)
+		{
+			long c = col_idx[j];
+			long q = c / padded;
+			if (c < 0 || q >= parts)
+			{
+				bad = 1;
+				continue;
+			}
+			long l = c - q * padded;
+			if (l < tlo[q]) tlo[q] = l;
+			if (l + 1 > thi[q]) thi[q] = l + 1;
+		}
+		#pragma omp critical
+		for (long q = 0; q < parts; q++)
+		{
+			lo[q] = std::min(lo[q], tlo[q]);
+			hi[q] = std::max(hi[q], thi[q]);
+		}
+	}
+	if (bad)
+	{
+		set_error("column index outside the padded layout");
+		return 1;
+	}
+	return 0;
+}
+
 }  // namespace spmv_host

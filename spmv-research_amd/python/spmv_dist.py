@@ -57,3 +57,45 @@ def scatter_x_padded(x_global, offsets, padded):
     for p in range(world):
         out[p * padded:p * padded + int(offsets[p + 1] - offsets[p])] = x_global[offsets[p]:offsets[p + 1]]
     return out
+
+
+def needed_ranges(col_idx_padded, padded, world):
+    """(lo, hi) per peer: the part of each peer's x slice this block references (hi == lo == 0: nothing)."""
+    return H.column_ranges(col_idx_padded, padded, world)
+
+
+class TrimmedExchange:
+    """x exchange that moves only what each row block reads: rank p receives from rank q the contiguous sub-range
+    [lo, hi) of q's slice that p's columns touch — grouped RCCL send/recv (batch_isend_irecv) straight into the padded
+    x buffer, no packing. Degenerates to the full allgather when every rank reads everything. The range table is
+    agreed once (one small all_gather), so sends and receives always match."""
+
+    def __init__(self, dist, x_full, padded, rank, world, lo, hi):
+        import torch
+        self.dist, self.x_full, self.padded, self.rank, self.world = dist, x_full, padded, rank, world
+        mine = torch.tensor(np.stack([lo, hi]).astype(np.int64))
+        table = [torch.zeros_like(mine) for _ in range(world)]
+        dev = x_full.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        mine_d = mine.to(dev)
+        table = [t.to(dev) for t in table]
+        dist.all_gather(table, mine_d)
+        self.need = np.stack([t.cpu().numpy() for t in table])            # need[p, 0/1, q]
+        self.recv_elems = int(sum(self.need[rank, 1, q] - self.need[rank, 0, q] for q in range(world) if q != rank))
+
+    def ops(self):
+        d, P, r, pad = self.dist, self.dist.P2POp, self.rank, self.padded
+        out = []
+        for q in range(self.world):
+            if q == r:
+                continue
+            lo, hi = int(self.need[r, 0, q]), int(self.need[r, 1, q])
+            if hi > lo:
+                out.append(P(d.irecv, self.x_full[q * pad + lo:q * pad + hi], q))
+            lo, hi = int(self.need[q, 0, r]), int(self.need[q, 1, r])
+            if hi > lo:
+                out.append(P(d.isend, self.x_full[r * pad + lo:r * pad + hi], q))
+        return out
+
+    def start(self):
+        ops = self.ops()
+        return self.dist.batch_isend_irecv(ops) if ops else []

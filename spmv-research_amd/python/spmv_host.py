@@ -12,7 +12,7 @@ SYMBOLS = [
     "spmv_host_last_error", "spmv_host_free", "spmv_host_mtx_read", "spmv_host_coo_free", "spmv_host_coo_to_csr",
     "spmv_host_mtx_write_csr", "spmv_host_partition_iterations", "spmv_host_partition_prefix_sums",
     "spmv_host_csr_free", "spmv_host_gen_twin", "spmv_host_gen_named", "spmv_host_gen_kkt", "spmv_host_csr_features",
-    "spmv_host_gen_kkt_row_ptr", "spmv_host_gen_kkt_block", "spmv_host_remap_columns",
+    "spmv_host_gen_kkt_row_ptr", "spmv_host_gen_kkt_block", "spmv_host_remap_columns", "spmv_host_column_ranges",
 ]
 
 
@@ -167,6 +167,17 @@ def remap_columns(col_idx, offsets, padded):
     _check(lib().spmv_host_remap_columns(_p(col_idx), C.c_long(len(col_idx)), _p(offsets), C.c_long(len(offsets) - 1),
                                          C.c_long(padded)))
     return col_idx
+
+
+def column_ranges(col_idx, padded, parts):
+    assert col_idx.dtype == np.int32 and col_idx.flags.c_contiguous
+    lo = np.zeros(parts, np.int64)
+    hi = np.zeros(parts, np.int64)
+    _check(lib().spmv_host_column_ranges(_p(col_idx), C.c_long(len(col_idx)), C.c_long(padded), C.c_long(parts), _p(lo), _p(hi)))
+    hi = np.maximum(hi, lo * 0)
+    lo = np.where(hi > lo, lo, 0)
+    hi = np.where(hi > lo, hi, 0)
+    return lo, hi
 
 
 FEATURES = ("avg_nnz_per_row", "std_nnz_per_row", "avg_bw_scaled", "skew", "avg_num_neighbours",

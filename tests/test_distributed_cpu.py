@@ -47,6 +47,17 @@ def _worker(rank, world, port, q):
             np.add.at(rp, rows[mask] + 1, 1)
             return np.cumsum(rp).astype(np.int32), blk["col_idx"][mask], blk["values"][mask]
         y = orc.csr_spmv(*sub(inside), xp) + orc.csr_spmv(*sub(~inside), xp)
+        # trimmed exchange (grouped send/recv of only the referenced sub-ranges) must deliver every x entry the block reads
+        lo, hi = D.needed_ranges(blk["col_idx"], padded, world)
+        x_trim = torch.zeros(world * padded, dtype=torch.float64)
+        x_trim[rank * padded:rank * padded + (r1 - r0)] = torch.from_numpy(x[r0:r1])
+        ex = D.TrimmedExchange(dist, x_trim, padded, rank, world, lo, hi)
+        for req in ex.start():
+            req.wait()
+        assert ex.recv_elems <= (world - 1) * padded
+        y_trim = orc.csr_spmv(blk["row_ptr"], blk["col_idx"], blk["values"], x_trim.numpy())
+        y_full = orc.csr_spmv(blk["row_ptr"], blk["col_idx"], blk["values"], xp)
+        np.testing.assert_array_equal(y_trim, y_full)
         ypad = torch.zeros(padded, dtype=torch.float64)             # validation only, not on the data path
         ypad[:r1 - r0] = torch.from_numpy(y)
         ys = [torch.zeros(padded, dtype=torch.float64) for _ in range(world)]
@@ -60,7 +71,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 3])
 def test_row_partition_allgather_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
