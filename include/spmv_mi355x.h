@@ -62,7 +62,7 @@ typedef struct {
 	int  sell_sigma;        /* SELL: sort window in rows (multiple of sell_c); 0 = 16384 (sell_c_s.cpp:58-60)      */
 	int  merge_items;       /* MERGE: merge items per thread (5,7,9,11,13); COO: entries per lane (2,4,8); 0 = default */
 	int  xcd_remap;         /* tile order over the 8 XCDs: 0 = auto, 1 = contiguous work-balanced ranges, 2 = off,
-	                           3 = chunks of 32 tiles dealt round-robin to the XCDs                                */
+	                           3 = chunks of 64 tiles dealt round-robin to the XCDs                                */
 	int  nontemporal;       /* matrix streams loaded with the nt policy: 0 = auto (by footprint), 1 = on, 2 = off  */
 	int  stream_mode;       /* CSR_STREAM: 0 = auto (3); 1 = products staged in LDS (row-major x gather); 2 = (value,column)
 	                           pairs staged in LDS through registers, lanes walk rows (coalesced x gathers); 3 = the same with

@@ -33,11 +33,13 @@ constexpr int NUM_XCD = 8;
 struct XcdMap {
 	unsigned start[NUM_XCD + 1];   // remap == 1: tile range per XCD group (balanced by work)
 	unsigned ntiles;
-	unsigned remap;                // 0 = identity, 1 = contiguous work-balanced ranges, 2 = chunks of XCD_CHUNK tiles dealt
+	unsigned remap;                // 0 = identity, 1 = contiguous work-balanced ranges, 2 = chunks of `chunk` tiles dealt
 	                               //     round-robin to the XCD groups (locality inside a chunk, balance by statistics)
+	unsigned chunk;                // tiles per chunk in mode 2 (power of two)
 };
 
-constexpr unsigned XCD_CHUNK = 32;
+// measured on the nlpkkt240 twin (SELL delta kernel): chunks of 32..128 tiles within 1 %, 8 tiles -17 %, >= 512 tiles -5..-13 %
+constexpr unsigned XCD_CHUNK_DEFAULT = 64;
 
 constexpr unsigned NO_TILE = 0xffffffffu;
 
@@ -50,7 +52,7 @@ xcd_tile(unsigned bid, const XcdMap & mp)
 	const unsigned i = bid / NUM_XCD;          // i-th block of this XCD group
 	if (mp.remap == 2)
 	{
-		const unsigned t = ((i / XCD_CHUNK) * NUM_XCD + k) * XCD_CHUNK + i % XCD_CHUNK;
+		const unsigned t = ((i / mp.chunk) * NUM_XCD + k) * mp.chunk + i % mp.chunk;
 		return t < mp.ntiles ? t : NO_TILE;
 	}
 	const unsigned t = mp.start[k] + i;
@@ -65,7 +67,7 @@ xcd_grid(const XcdMap & mp)
 		return mp.ntiles;
 	if (mp.remap == 2)
 	{
-		const unsigned span = NUM_XCD * XCD_CHUNK;
+		const unsigned span = NUM_XCD * mp.chunk;
 		return (mp.ntiles + span - 1) / span * span;
 	}
 	unsigned mx = 0;
@@ -81,6 +83,7 @@ xcd_map_uniform(unsigned ntiles, int remap)
 	XcdMap mp;
 	mp.ntiles = ntiles;
 	mp.remap = (unsigned) remap;
+	mp.chunk = XCD_CHUNK_DEFAULT;
 	for (int k = 0; k <= NUM_XCD; k++)
 		mp.start[k] = (unsigned) ((unsigned long long) ntiles * k / NUM_XCD);
 	return mp;
@@ -96,6 +99,7 @@ xcd_map_balanced(const P * prefix, long num_units, long units_per_tile, int rema
 	const long ntiles = (num_units + units_per_tile - 1) / units_per_tile;
 	mp.ntiles = (unsigned) ntiles;
 	mp.remap = (unsigned) remap;
+	mp.chunk = XCD_CHUNK_DEFAULT;
 	const double total = (double) (prefix[num_units] - prefix[0]);
 	mp.start[0] = 0;
 	for (int k = 1; k < NUM_XCD; k++)

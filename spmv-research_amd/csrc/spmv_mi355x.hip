@@ -166,7 +166,7 @@ pick_lanes_per_row(double mean)
 }
 
 // auto tile order: contiguous work-balanced ranges keep each XCD's L2 on one window of x (best for small and skewed
-// matrices); for many-tile matrices chunks of 32 tiles dealt round-robin balance row-count-bound kernels better
+// matrices); for many-tile matrices chunks of 64 tiles dealt round-robin balance row-count-bound kernels better
 // (nlpkkt240 twin: csr_vector +26 %, csr_stream +12 %, SELL +2 %; pwtk/soc-LiveJournal1 twins prefer the ranges)
 static int
 resolve_remap(int requested, long ntiles)

@@ -78,8 +78,13 @@ def main():
                             print("skip", fmt, oo, e)
                             continue
                         s = torch.cuda.current_stream().cuda_stream
-                        M.time_device(x.data_ptr(), y.data_ptr(), 5, s)
-                        ms = min(M.time_device(x.data_ptr(), y.data_ptr(), args.iters, s) for _ in range(3))
+                        # warm up for >= 0.25 s (clocks, caches; the reference warms GPU kernels with 1000 calls), then the
+                        # median of 7 batches: single short bursts were seen to be bimodal on small matrices
+                        t_w = time.time()
+                        it = max(args.iters, 20)
+                        while time.time() - t_w < 0.25:
+                            M.time_device(x.data_ptr(), y.data_ptr(), it, s)
+                        ms = float(np.median([M.time_device(x.data_ptr(), y.data_ptr(), it, s) for _ in range(7)]))
                         gbps = B / ms / 1e6
                         rec = dict(workload=w, dtype=dts, format=M.format_name, opts=oo, ms=ms, gbps=gbps,
                                    gflops=2 * nnz / ms / 1e6, frac=gbps / 8000, mem_ratio=M.mem_footprint / M.csr_mem_footprint)
