@@ -44,12 +44,16 @@ def main():
     ap.add_argument("--formats", default="")
     ap.add_argument("--nt", default="0", help="comma list of nontemporal settings (0 auto,1 on,2 off)")
     ap.add_argument("--remap", default="0", help="comma list of xcd_remap settings (0 auto/on, 2 off)")
+    ap.add_argument("--cold", action="store_true",
+                    help="GPU analogue of the reference's CLEAR_CACHES (bench_spmv.cpp:331-348): overwrite a 1 GiB buffer "
+                         "(4x the 256 MiB Infinity Cache) before every launch and time single launches")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import torch
     import spmv_host as H
     import spmv_mi355x as E
     rows = []
+    flush = None
     for w in args.workloads.split(","):
         t = time.time()
         A = H.gen_named(w, args.scale)
@@ -85,6 +89,14 @@ def main():
                         while time.time() - t_w < 0.25:
                             M.time_device(x.data_ptr(), y.data_ptr(), it, s)
                         ms = float(np.median([M.time_device(x.data_ptr(), y.data_ptr(), it, s) for _ in range(7)]))
+                        if args.cold:
+                            if flush is None:
+                                flush = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+                            cold = []
+                            for rep in range(15):
+                                flush.fill_(float(rep))
+                                cold.append(M.time_device(x.data_ptr(), y.data_ptr(), 1, s))
+                            ms = float(np.median(cold))
                         gbps = B / ms / 1e6
                         rec = dict(workload=w, dtype=dts, format=M.format_name, opts=oo, ms=ms, gbps=gbps,
                                    gflops=2 * nnz / ms / 1e6, frac=gbps / 8000, mem_ratio=M.mem_footprint / M.csr_mem_footprint)
