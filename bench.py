@@ -297,6 +297,32 @@ def main():
                 dist.all_gather_into_tensor(x_full, x_send)
                 torch.cuda.synchronize()
         del x_expect
+    comm_only_ms = kernels_only_ms = None
+    if world > 1:
+        # untimed breakdown for the scaling report: the exchange alone and the two kernels alone
+        def comm_only():
+            for r in (exch.start() if use_p2p else [dist.all_gather_into_tensor(x_full, x_send, async_op=True)]):
+                r.wait()
+
+        def kernels_only():
+            mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
+            if args.overlap:
+                mats[1].spmv_device(x_full.data_ptr(), y.data_ptr(), 1, sp)
+
+        parts = []
+        for fn in (comm_only, kernels_only):
+            for _ in range(3):
+                fn()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            parts.append(float(tt.item()) / 10 * 1e3)
+        comm_only_ms, kernels_only_ms = parts
     for _ in range(args.warmup):
         step()
     barrier()
@@ -373,6 +399,8 @@ def main():
                      "algorithmic_bytes_per_launch": int(B_alg_local)},
         "check_max_err_over_abs_row": max_rel,
         "exchange": exchange_info,
+        "breakdown_ms": None if world == 1 else {"exchange_alone": round(comm_only_ms, 4), "kernels_alone": round(kernels_only_ms, 4),
+                                                 "overlap_efficiency": round((comm_only_ms + kernels_only_ms) / ms_per_step, 3)},
         "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t_conv, 2)},
     }
 
@@ -398,8 +426,14 @@ def main():
         if chk:
             dmax = float(np.max(np.abs(ys[chk] - yh[chk]) / np.maximum(np.abs(yh[chk]), 1e-300)))
             assert dmax < 1e-9 or dts == "f32", f"CPU baseline result differs from the GPU result ({dmax})"
+        cpu_model = ""
+        try:
+            with open("/proc/cpuinfo") as fh:
+                cpu_model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "")
+        except OSError:
+            pass
         result["cpu_baseline"] = {"value": round(2.0 * snnz / tb["median"] / 1e9, 3), "unit": "GFLOP/s",
-                                  "cores": cores, "kind": "port", "sample": sample,
+                                  "cores": cores, "cpu_model": cpu_model, "kind": "port", "sample": sample,
                                   "median_s": tb["median"], "loops": tb["loops"],
                                   "gbps": round(algorithmic_bytes(rs, n, snnz, 8) / tb["median"] / 1e9, 2)}
     if rank == 0:
