@@ -96,6 +96,8 @@ double spmv_mi355x_csr_mem_footprint(const spmv_mi355x_matrix * A);  /* nnz*(siz
 long   spmv_mi355x_rows(const spmv_mi355x_matrix * A);               /* local rows (row block)                      */
 long   spmv_mi355x_cols(const spmv_mi355x_matrix * A);
 long   spmv_mi355x_nnz(const spmv_mi355x_matrix * A);                /* local non-zeros after row/column filtering  */
+int    spmv_mi355x_precision(const spmv_mi355x_matrix * A);          /* SPMV_MI355X_F64 / SPMV_MI355X_F32           */
+int    spmv_mi355x_device(const spmv_mi355x_matrix * A);             /* HIP device ordinal the handle lives on      */
 
 /* ---- Matrix_Format::spmv(x, y) with HOST buffers --------------------------------------------------------- */
 /* Reference GPU-backend semantics (GPU_clean/csr_rocm_vector.cpp:224-257): x is uploaded when the host
@@ -119,6 +121,32 @@ int  spmv_mi355x_kernel_info(const spmv_mi355x_matrix * A, char * name_out, long
 /* Device buffers owned by the handle (allocated lazily by the host-buffer entry points). */
 void * spmv_mi355x_x_device(spmv_mi355x_matrix * A);
 void * spmv_mi355x_y_device(spmv_mi355x_matrix * A);
+
+/* ---- solver callers of spmv() ---------------------------------------------------------------- */
+/* Device-resident replacements for the reference's two Krylov drivers, which call MF->spmv() with a vector that changes
+ * every iteration:  spmv_mi355x_pcg       = preconditioned_cg()        benchmark_code/BENCH/src/bench_cg.cpp:93-322
+ *                   spmv_mi355x_pbicgstab = preconditioned_bicgstab()  benchmark_code/BENCH/src/bench_bicg.cpp:149-459
+ * Arguments as in the reference: the handle (MF), the host CSR arrays the Jacobi preconditioner K = diag(A) is read from
+ * (values in fp64 = ValueTypeReference, like spmv_mi355x_create), b and x_res_out as HOST arrays of the handle's
+ * precision, max_iterations (CG_MAX_NUM_ITERS). Same semantics: x0 = 0, eps = 1e-15*|b|, explicit residual every 100
+ * iterations with best-x tracking, CG restart rule and `err < eps` break, BiCGSTAB never breaks; errors "bad K, zero in
+ * diagonal" and "the matrix must be square" are returned (rc 1 + last_error) instead of exit(1).
+ * history_out (may be NULL): 3*max_iterations doubles; row k = error, error_explicit, error_best as the reference prints
+ * them at iteration k (bench_cg.cpp:249); rows >= info->iterations stay 0. */
+typedef struct {
+	unsigned struct_size;      /* in: sizeof(spmv_mi355x_solver_info) */
+	long   iterations;         /* num_loops_out (bench_cg.cpp:315) */
+	double error;              /* |b - A*x_res_out|, the CSV "error" column (bench_cg.cpp:412-418) */
+	double error_best;         /* err_best: smallest explicit residual seen = the one of x_res_out */
+	double eps, eps_counter;   /* 1e-15*|b|, 1e-7*|b| (bench_cg.cpp:159-174) */
+	long   restarts;           /* CG restarts taken (bench_cg.cpp:219-235) */
+	long   spmv_calls;         /* SpMV launches the solver made */
+	double seconds;            /* wall time of the whole call = the CSV "time" column */
+} spmv_mi355x_solver_info;
+int  spmv_mi355x_pcg(spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t * col_idx, const double * values_fp64,
+		const void * b_host, void * x_res_out_host, long max_iterations, double * history_out, spmv_mi355x_solver_info * info);
+int  spmv_mi355x_pbicgstab(spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t * col_idx, const double * values_fp64,
+		const void * b_host, void * x_res_out_host, long max_iterations, double * history_out, spmv_mi355x_solver_info * info);
 
 /* ---- format introspection for parity tests (host copies of the converted arrays) -------------------------- */
 /* SELL-C-sigma layout: any out pointer may be NULL. Arrays are malloc'ed copies; free with spmv_mi355x_free().

@@ -114,6 +114,14 @@ double orc_time_csr_spmv_f64(const int32_t * row_ptr, const int32_t * col_idx, c
 		const double * x, double * y, int num_threads, long min_loops, double min_runtime,
 		long * loops_out, double * tmin_out, double * tmax_out);
 
+/* ---- solver callers of spmv() — PARITY UNPINNED (bench_cg.cpp / bench_bicg.cpp do not compile here; see
+ *      solver_oracle.c). history: 3 doubles per loop (error, error_explicit, error_best); info_out[4] =
+ *      {eps, eps_counter, err_best, restarts}; return num_loops_out, -1 zero diagonal, -2 not square. */
+long orc_pcg_f64(const int * row_ptr, const int * col, const double * val, long m, long n, const double * b,
+		double * x_out, long max_iterations, double * history, double * info_out);
+long orc_pbicgstab_f64(const int * row_ptr, const int * col, const double * val, long m, long n, const double * b,
+		double * x_out, long max_iterations, double * history, double * info_out);
+
 #ifdef __cplusplus
 }
 #endif

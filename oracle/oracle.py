@@ -232,3 +232,32 @@ def time_csr_spmv(row_ptr, col_idx, a, x, num_threads, min_loops=64, min_runtime
                                       C.c_int(num_threads), C.c_long(min_loops), C.c_double(min_runtime),
                                       C.byref(loops), C.byref(tmin), C.byref(tmax))
     return dict(median=med, min=tmin.value, max=tmax.value, loops=loops.value, y=y[:m].copy())
+
+
+def _solve(fn, row_ptr, col_idx, a, b, max_iterations):
+    row_ptr, col_idx = _i32(row_ptr), _i32(col_idx)
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    m = len(row_ptr) - 1
+    x = np.zeros(max(m, 1), np.float64)
+    hist = np.zeros((max(max_iterations, 1), 3), np.float64)
+    info = np.zeros(4, np.float64)
+    fn.restype = C.c_long
+    k = fn(_p(row_ptr), _p(col_idx), _p(a), C.c_long(m), C.c_long(len(b)), _p(b), _p(x), C.c_long(max_iterations),
+           _p(hist), _p(info))
+    if k == -1:
+        raise ValueError("bad K, zero in diagonal")
+    if k == -2:
+        raise ValueError("the matrix must be square")
+    return dict(x=x[:m], iterations=int(k), history=hist[:k], eps=info[0], eps_counter=info[1], err_best=info[2],
+                restarts=int(info[3]))
+
+
+def pcg(row_ptr, col_idx, a, b, max_iterations):
+    """Jacobi-preconditioned CG as bench_cg.cpp:93-322 (one thread). PARITY UNPINNED, see solver_oracle.c."""
+    return _solve(lib().orc_pcg_f64, row_ptr, col_idx, a, b, max_iterations)
+
+
+def pbicgstab(row_ptr, col_idx, a, b, max_iterations):
+    """Jacobi-preconditioned BiCGSTAB as bench_bicg.cpp:149-459 (one thread). PARITY UNPINNED."""
+    return _solve(lib().orc_pbicgstab_f64, row_ptr, col_idx, a, b, max_iterations)

@@ -864,6 +864,8 @@ double spmv_mi355x_csr_mem_footprint(const spmv_mi355x_matrix * A) { return A->c
 long spmv_mi355x_rows(const spmv_mi355x_matrix * A) { return A->m; }
 long spmv_mi355x_cols(const spmv_mi355x_matrix * A) { return A->n; }
 long spmv_mi355x_nnz(const spmv_mi355x_matrix * A) { return A->nnz; }
+int spmv_mi355x_precision(const spmv_mi355x_matrix * A) { return A->precision; }
+int spmv_mi355x_device(const spmv_mi355x_matrix * A) { return A->device; }
 
 int
 spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, int beta, void * hip_stream)

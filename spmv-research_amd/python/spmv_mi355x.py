@@ -35,7 +35,8 @@ SYMBOLS = [
     "spmv_mi355x_rows", "spmv_mi355x_cols", "spmv_mi355x_nnz", "spmv_mi355x_spmv", "spmv_mi355x_set_always_copy",
     "spmv_mi355x_upload_x", "spmv_mi355x_download_y", "spmv_mi355x_spmv_device_async", "spmv_mi355x_time_device",
     "spmv_mi355x_kernel_info", "spmv_mi355x_x_device", "spmv_mi355x_y_device", "spmv_mi355x_sell_layout",
-    "spmv_mi355x_merge_tiles", "spmv_mi355x_free",
+    "spmv_mi355x_merge_tiles", "spmv_mi355x_free", "spmv_mi355x_precision", "spmv_mi355x_device",
+    "spmv_mi355x_pcg", "spmv_mi355x_pbicgstab",
 ]
 
 _lib = None
@@ -91,6 +92,13 @@ def device_info(device=0):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class SolverInfo(C.Structure):
+    """spmv_mi355x_solver_info (include/spmv_mi355x.h)"""
+    _fields_ = [("struct_size", C.c_uint), ("iterations", C.c_long), ("error", C.c_double), ("error_best", C.c_double),
+                ("eps", C.c_double), ("eps_counter", C.c_double), ("restarts", C.c_long), ("spmv_calls", C.c_long),
+                ("seconds", C.c_double)]
 
 
 class Matrix:
@@ -193,6 +201,31 @@ class Matrix:
         coords = np.ctypeslib.as_array(co, shape=(2 * (nt.value + 1),)).copy().reshape(-1, 2)
         lib().spmv_mi355x_free(co)
         return dict(num_tiles=nt.value, tile_items=ti.value, coords=coords)
+
+    def _solve(self, fn, row_ptr, col_idx, values, b, max_iterations, history):
+        row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+        col_idx = np.ascontiguousarray(col_idx, np.int32)
+        values = np.ascontiguousarray(values, np.float64)
+        b = np.ascontiguousarray(b, self.dtype)
+        assert b.shape[0] == self.m and len(row_ptr) == self.m + 1
+        x = np.zeros(max(self.n, 1), self.dtype)
+        hist = np.zeros((max(max_iterations, 1), 3), np.float64) if history else None
+        info = SolverInfo()
+        info.struct_size = C.sizeof(SolverInfo)
+        _check(fn(self.h, _p(row_ptr), _p(col_idx), _p(values), _p(b), _p(x), C.c_long(max_iterations),
+                  _p(hist) if history else None, C.byref(info)))
+        out = {k: getattr(info, k) for k, _ in SolverInfo._fields_ if k != "struct_size"}
+        out["x"] = x[:self.n]
+        out["history"] = hist[:info.iterations] if history else None
+        return out
+
+    def pcg(self, row_ptr, col_idx, values, b, max_iterations, history=True):
+        """preconditioned_cg() of bench_cg.cpp:93-322 with every vector resident in HBM."""
+        return self._solve(lib().spmv_mi355x_pcg, row_ptr, col_idx, values, b, max_iterations, history)
+
+    def pbicgstab(self, row_ptr, col_idx, values, b, max_iterations, history=True):
+        """preconditioned_bicgstab() of bench_bicg.cpp:149-459 with every vector resident in HBM."""
+        return self._solve(lib().spmv_mi355x_pbicgstab, row_ptr, col_idx, values, b, max_iterations, history)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
