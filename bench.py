@@ -73,7 +73,7 @@ def kkt_edge(scale):
     return max(4, int(round(240 * scale ** (1.0 / 3.0))))
 
 
-def load_traffic(workload, fmt, dtype):
+def load_traffic(workload, fmt, dtype, kernel):
     """HBM bytes per launch from the rocprofv3 PMC passes (tools/collect_traffic.py -> profiles/traffic_*.json)."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
@@ -84,21 +84,39 @@ def load_traffic(workload, fmt, dtype):
             try:
                 with open(os.path.join(pdir, f)) as fh:
                     for rec in json.load(fh).get("records", []):
+                        # the record must be of the kernel that actually ran (a non-default option set, e.g. plain
+                        # SELL instead of the delta layout, is a different kernel with different traffic)
                         if rec.get("workload") == workload and rec.get("format") == fmt and rec.get("dtype") == dtype \
-                                and rec.get("scale", 1.0) == 1.0:
+                                and rec.get("scale", 1.0) == 1.0 and rec.get("kernel", "").split("<")[0] == kernel:
                             best = rec.get("hbm_bytes_per_launch")
             except Exception:
                 pass
     return best
 
 
+def cpu_share():
+    """cores this job may use: the cgroup CPU quota when there is one, else the affinity mask"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     args = parse()
-    # torch.distributed.run pins OMP_NUM_THREADS=1 for its children; the host-side generation / format conversion is
-    # OpenMP code, so give each rank its share of the cores back before any OpenMP runtime starts
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
-        share = max(1, min(16, len(os.sched_getaffinity(0)) // int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))))
-        os.environ["OMP_NUM_THREADS"] = str(share)
+    # Host threads: the GPU box shows all 256 cores but a job owns a cgroup CPU quota (16 cores per GPU); an OpenMP team
+    # of 256 burns the quota in a few ms and the kernel then freezes the whole process — the thread feeding the GPU
+    # included — until the next 100 ms period (csrc/host_threads.hpp has the measurement). torch.distributed.run on the
+    # other hand pins OMP_NUM_THREADS=1. Either way: give every rank its share, before any OpenMP runtime starts.
+    share = max(1, min(cpu_share(), len(os.sched_getaffinity(0))) // int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    if "OMP_NUM_THREADS" not in os.environ or (int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ["OMP_NUM_THREADS"] == "1"):
+        os.environ["OMP_NUM_THREADS"] = str(min(share, 16) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else share)
+    os.environ.setdefault("KMP_BLOCKTIME", "0")
     import torch
     import spmv_host as H
     import spmv_mi355x as E
@@ -394,7 +412,7 @@ def main():
         "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 2),
         "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(ach / HBM_PEAK_GBPS, 4),
-                     "traffic": load_traffic(workload, fmt, dts) if world == 1 and args.scale == 1.0 else None,
+                     "traffic": load_traffic(workload, fmt, dts, ki["name"]) if world == 1 and args.scale == 1.0 else None,
                      "kernel": ki["name"], "kernel_ms": round(kernel_ms, 6),
                      "algorithmic_bytes_per_launch": int(B_alg_local)},
         "check_max_err_over_abs_row": max_rel,
@@ -409,7 +427,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as orc                                  # checker only: timed beside the GPU, never shipped
         # the GPU box shows every host CPU but one GPU's share is 16 cores (oversubscribing 256 threads is 10x slower)
-        cores = int(os.environ.get("SPMV_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+        cores = int(os.environ.get("SPMV_CPU_THREADS", min(cpu_share(), 16)))
         max_nnz = 64_000_000
         if lnnz > max_nnz:
             rs = int(np.searchsorted(rp, max_nnz))

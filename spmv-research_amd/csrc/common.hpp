@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include "host_threads.hpp"
+
 namespace spmv {
 
 // ------------------------------------------------------------------------------------------------ errors

@@ -11,8 +11,10 @@
 //   * dots are two-stage: every block writes one partial per quantity, and every block of the CONSUMING kernel re-reduces
 //     the <= 1024 partials in a fixed order — deterministic, and no separate "finish the reduction" launch;
 //   * the `err < eps` break (bench_cg.cpp:238) becomes a device flag that predicates every later vector kernel off, so
-//     x, x_best, the counter and the history are frozen exactly where the reference breaks; the host polls the flag
-//     every POLL iterations from a pinned copy and stops enqueueing;
+//     x, x_best, the counter and the history are frozen exactly where the reference breaks; the last kernel of every
+//     iteration also posts (iterations finished, done) into host-mapped pinned memory, which the host READS (no HIP call:
+//     hipEventSynchronize in this loop was measured to stall the queue for up to 100 ms at a time) to stop enqueueing
+//     after a break and to stay at most 2*POLL iterations ahead of the device;
 //   * the vector updates around the SpMV are fused: CG = SpMV + 3 passes (p.Ap | x,r update + z.r, r.r | p update),
 //     BiCGSTAB = 2 SpMV + 5 passes. z = r/K and h = x + s_a*y are never materialised.
 // Same iteration semantics as the reference: Jacobi K = first stored diagonal entry (error on a zero), x0 = 0,
@@ -22,6 +24,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -33,7 +36,7 @@ namespace spmv {
 constexpr int VB = 256;           // threads per block of the vector kernels
 constexpr int MAX_PART = 1024;    // partial sums per quantity
 constexpr int RESTART_K = 100;    // bench_cg.cpp:178
-constexpr int POLL = 32;          // iterations between host polls of the `done` flag
+constexpr int POLL = 32;          // the host looks at the progress word every POLL iterations
 
 struct SolverState {
 	double err, err_explicit, err_best, eps, eps_counter;
@@ -85,6 +88,16 @@ store_partial(double * __restrict__ part, int slot, double v)
 	v = block_sum(v);
 	if (threadIdx.x == 0)
 		part[(long) slot * MAX_PART + blockIdx.x] = v;
+}
+
+// (iterations the device has finished, break flag) for the host, in host-mapped pinned memory
+__device__ __forceinline__ void
+post_progress(volatile long * host_progress, long finished, int done)
+{
+	host_progress[1] = done;
+	__threadfence_system();
+	host_progress[0] = finished;
+	__threadfence_system();
 }
 
 #define GRID_STRIDE(i, m) for (long i = (long) blockIdx.x * VB + threadIdx.x; i < (m); i += (long) gridDim.x * VB)
@@ -274,13 +287,17 @@ cg_update_kernel(const SolverState * __restrict__ st_p, T * __restrict__ x, T * 
 template <typename T>
 __global__ __launch_bounds__(VB) void
 cg_direction_kernel(const SolverState * __restrict__ st_p, SolverState * __restrict__ st_next, const T * __restrict__ r,
-		T * __restrict__ p, const T * __restrict__ K, long m, int nb, const double * __restrict__ part)
+		T * __restrict__ p, const T * __restrict__ K, long m, int nb, const double * __restrict__ part, long it,
+		volatile long * host_progress)
 {
 	const SolverState st = *st_p;
 	if (st.done)
 	{
 		if (blockIdx.x == 0 && threadIdx.x == 0)
+		{
 			*st_next = st;
+			post_progress(host_progress, it + 1, 1);
+		}
 		return;
 	}
 	const double zr_new = sum_partials(part, P_D, nb);
@@ -298,6 +315,7 @@ cg_direction_kernel(const SolverState * __restrict__ st_p, SolverState * __restr
 			nx.k = st.k + 1;
 			nx.done = nx.err < nx.eps;
 			*st_next = nx;
+			post_progress(host_progress, it + 1, nx.done);
 		}
 	}
 }
@@ -401,7 +419,7 @@ template <typename T>
 __global__ __launch_bounds__(VB) void
 bicg_direction_kernel(const SolverState * __restrict__ st_p, SolverState * __restrict__ st_next, const T * __restrict__ r,
 		const T * __restrict__ v, const T * __restrict__ K, T * __restrict__ p, T * __restrict__ y, long m, int nb,
-		const double * __restrict__ part)
+		const double * __restrict__ part, long it, volatile long * host_progress)
 {
 	const SolverState st = *st_p;
 	const T s_pk_p = (T) st.zr;
@@ -426,6 +444,7 @@ bicg_direction_kernel(const SolverState * __restrict__ st_p, SolverState * __res
 			nx.err = sqrt(rr);
 			nx.k = st.k + 1;
 			*st_next = nx;
+			post_progress(host_progress, it + 1, 0);
 		}
 	}
 }
@@ -435,16 +454,12 @@ bicg_direction_kernel(const SolverState * __restrict__ st_p, SolverState * __res
 struct DeviceBuffers {
 	std::vector<void *> ptrs;
 	void * pinned = nullptr;
-	hipEvent_t ev[2] = {nullptr, nullptr};
 	~DeviceBuffers()
 	{
 		for (void * p : ptrs)
 			(void) hipFree(p);
 		if (pinned)
 			(void) hipHostFree(pinned);
-		for (auto & e : ev)
-			if (e)
-				(void) hipEventDestroy(e);
 	}
 	template <typename P>
 	int alloc(P ** out, size_t bytes)
@@ -463,7 +478,7 @@ static long
 jacobi_diagonal(const int32_t * row_ptr, const int32_t * col, const double * val, long m, T * K)
 {
 	long bad = -1;
-	#pragma omp parallel for schedule(static)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static)
 	for (long i = 0; i < m; i++)
 	{
 		T k = 0;
@@ -525,11 +540,12 @@ solve(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t
 		ABI_TRY(buf.alloc(&history, sizeof(double) * 3 * (size_t) max_iterations));
 		HIP_TRY(hipMemsetAsync(history, 0, sizeof(double) * 3 * (size_t) max_iterations, stream));
 	}
-	HIP_TRY(hipHostMalloc(&buf.pinned, 2 * sizeof(SolverState), hipHostMallocDefault));
-	SolverState * polled = (SolverState *) buf.pinned;
-	memset(polled, 0, 2 * sizeof(SolverState));
-	for (auto & e : buf.ev)
-		HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	HIP_TRY(hipHostMalloc(&buf.pinned, 2 * sizeof(long), hipHostMallocMapped | hipHostMallocCoherent));
+	volatile long * progress = (volatile long *) buf.pinned;          // [0] iterations finished, [1] break flag
+	progress[0] = 0;
+	progress[1] = 0;
+	long * progress_dev = nullptr;
+	HIP_TRY(hipHostGetDevicePointer((void **) &progress_dev, buf.pinned, 0));
 
 	HIP_TRY(hipMemcpyAsync(b, b_host, vb, hipMemcpyHostToDevice, stream));
 	HIP_TRY(hipMemcpyAsync(K, K_host.data(), vb, hipMemcpyHostToDevice, stream));
@@ -562,51 +578,72 @@ solve(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t
 	hipLaunchKernelGGL(init_state_kernel, one, block, 0, stream, st, nb, method, part);
 	HIP_TRY(hipGetLastError());
 
+	const bool debug = getenv("SPMV_MI355X_SOLVER_DEBUG") != nullptr;
+	double t_spin = 0;
+	const auto t_loop = std::chrono::steady_clock::now();
 	long it = 0;
-	int chunk = 0;
-	bool stop = false;
-	while (it < max_iterations && !stop)
+	for (; it < max_iterations; it++)
 	{
-		const long it_end = std::min(max_iterations, it + POLL);
-		for (; it < it_end; it++)
+		if (it % POLL == 0 && it >= 2 * POLL)
 		{
-			SolverState * cur = st + (it & 1), * nxt = st + ((it + 1) & 1);
-			if (it > 0 && it % RESTART_K == 0)
+			// stay at most 2*POLL iterations ahead; plain reads of the mapped word, no HIP call
+			const auto t_wait = std::chrono::steady_clock::now();
+			long spins = 0;
+			while (progress[0] < it - POLL)
 			{
-				ABI_TRY(explicit_residual(x));
-				hipLaunchKernelGGL((explicit_kernel<T>), grid, block, 0, stream, cur, x, x_best, r_explicit, r, p, K, m, nb,
-						method == 0, 0, part);
-				hipLaunchKernelGGL(explicit_fin_kernel, one, block, 0, stream, cur, nb, method == 0, 0, part);
+				if ((++spins & 0xfff) == 0)
+				{
+					HIP_TRY(hipGetLastError());
+					if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() > 120.0)
+					{
+						set_error("solver: the device made no progress for 120 s at iteration %ld", it);
+						(void) hipStreamSynchronize(stream);
+						return 1;
+					}
+				}
+				__builtin_ia32_pause();
 			}
-			if (method == 0)
-			{
-				ABI_TRY(spmv(p, Ap));
-				hipLaunchKernelGGL((cg_dot_kernel<T>), grid, block, 0, stream, cur, p, Ap, m, history, it, part);
-				hipLaunchKernelGGL((cg_update_kernel<T>), grid, block, 0, stream, cur, x, r, p, Ap, K, m, nb, part);
-				hipLaunchKernelGGL((cg_direction_kernel<T>), grid, block, 0, stream, cur, nxt, r, p, K, m, nb, part);
-			}
-			else
-			{
-				ABI_TRY(spmv(y, v));
-				hipLaunchKernelGGL((bicg_dot_kernel<T>), grid, block, 0, stream, cur, r0, v, m, history, it, part);
-				hipLaunchKernelGGL((bicg_s_kernel<T>), grid, block, 0, stream, cur, r, v, K, s, z, m, nb, part);
-				ABI_TRY(spmv(z, Ap));                                // t = A z
-				hipLaunchKernelGGL((bicg_omega_kernel<T>), grid, block, 0, stream, Ap, s, K, m, part);
-				hipLaunchKernelGGL((bicg_update_kernel<T>), grid, block, 0, stream, cur, s, Ap, y, z, r0, r, x, m, nb, part);
-				hipLaunchKernelGGL((bicg_direction_kernel<T>), grid, block, 0, stream, cur, nxt, r, v, K, p, y, m, nb, part);
-			}
+			t_spin += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+			if (progress[1])
+				break;
 		}
-		HIP_TRY(hipGetLastError());
-		// poll: copy the state after this chunk; look at the copy of the PREVIOUS chunk (already complete or nearly so),
-		// so the queue always holds at least one chunk of work and the device never waits for the host.
-		HIP_TRY(hipMemcpyAsync(polled + (chunk & 1), st + (it & 1), sizeof(SolverState), hipMemcpyDeviceToHost, stream));
-		HIP_TRY(hipEventRecord(buf.ev[chunk & 1], stream));
-		if (chunk > 0)
+		SolverState * cur = st + (it & 1), * nxt = st + ((it + 1) & 1);
+		if (it > 0 && it % RESTART_K == 0)
 		{
-			HIP_TRY(hipEventSynchronize(buf.ev[(chunk - 1) & 1]));
-			stop = polled[(chunk - 1) & 1].done != 0;
+			ABI_TRY(explicit_residual(x));
+			hipLaunchKernelGGL((explicit_kernel<T>), grid, block, 0, stream, cur, x, x_best, r_explicit, r, p, K, m, nb,
+					method == 0, 0, part);
+			hipLaunchKernelGGL(explicit_fin_kernel, one, block, 0, stream, cur, nb, method == 0, 0, part);
 		}
-		chunk++;
+		if (method == 0)
+		{
+			ABI_TRY(spmv(p, Ap));
+			hipLaunchKernelGGL((cg_dot_kernel<T>), grid, block, 0, stream, cur, p, Ap, m, history, it, part);
+			hipLaunchKernelGGL((cg_update_kernel<T>), grid, block, 0, stream, cur, x, r, p, Ap, K, m, nb, part);
+			hipLaunchKernelGGL((cg_direction_kernel<T>), grid, block, 0, stream, cur, nxt, r, p, K, m, nb, part, it, progress_dev);
+		}
+		else
+		{
+			ABI_TRY(spmv(y, v));
+			hipLaunchKernelGGL((bicg_dot_kernel<T>), grid, block, 0, stream, cur, r0, v, m, history, it, part);
+			hipLaunchKernelGGL((bicg_s_kernel<T>), grid, block, 0, stream, cur, r, v, K, s, z, m, nb, part);
+			ABI_TRY(spmv(z, Ap));                                // t = A z
+			hipLaunchKernelGGL((bicg_omega_kernel<T>), grid, block, 0, stream, Ap, s, K, m, part);
+			hipLaunchKernelGGL((bicg_update_kernel<T>), grid, block, 0, stream, cur, s, Ap, y, z, r0, r, x, m, nb, part);
+			hipLaunchKernelGGL((bicg_direction_kernel<T>), grid, block, 0, stream, cur, nxt, r, v, K, p, y, m, nb, part, it,
+					progress_dev);
+		}
+	}
+	HIP_TRY(hipGetLastError());
+	const auto t_loop_end = std::chrono::steady_clock::now();
+	if (debug)
+	{
+		HIP_TRY(hipStreamSynchronize(stream));
+		const auto t_sync = std::chrono::steady_clock::now();
+		fprintf(stderr, "[solver] setup %.3f ms, enqueue loop %.3f ms (spin %.3f ms), drain %.3f ms, %ld iterations launched\n",
+				std::chrono::duration<double>(t_loop - t_start).count() * 1e3,
+				std::chrono::duration<double>(t_loop_end - t_loop).count() * 1e3, t_spin * 1e3,
+				std::chrono::duration<double>(t_sync - t_loop_end).count() * 1e3, it);
 	}
 
 	// final explicit residual of x, promotion of x_best (bench_cg.cpp:288-306); runs after a break too
@@ -640,6 +677,9 @@ solve(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t
 		out.restarts = st_host.restarts;
 		out.spmv_calls = spmv_calls - 1;                          // the last one is the harness's check, not the solver's
 		out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+		if (debug)
+			fprintf(stderr, "[solver] tail (final residuals, downloads) %.3f ms, total %.3f ms\n",
+					std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop_end).count() * 1e3, out.seconds * 1e3);
 		const unsigned want = info->struct_size;
 		out.struct_size = sizeof(out);
 		memcpy(info, &out, std::min<size_t>(want, sizeof(out)));

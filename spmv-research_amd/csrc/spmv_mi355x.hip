@@ -134,7 +134,7 @@ upload_values(spmv_mi355x_matrix * A, const double * v, size_t count, void ** d_
 	for (size_t off = 0; off < count; off += CH)
 	{
 		size_t len = std::min(CH, count - off);
-		#pragma omp parallel for
+		#pragma omp parallel for num_threads(spmv::host_threads())
 		for (long i = 0; i < (long) len; i++)
 			tmp[i] = (float) v[off + i];
 		HIP_TRY(hipMemcpy((char *) *d_out + off * sizeof(float), tmp.data(), len * sizeof(float), hipMemcpyHostToDevice));
@@ -189,7 +189,7 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 	const long num_slices = (m + C - 1) / C;
 	std::vector<int> row_of_sorted(std::max<long>(m, 1));
 	const long num_windows = (m + sigma - 1) / sigma;
-	#pragma omp parallel for schedule(dynamic, 4)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4)
 	for (long w = 0; w < num_windows; w++)
 	{
 		long s = w * sigma, e = std::min(m, s + sigma);
@@ -206,7 +206,7 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 			row_of_sorted[s + cnt[maxlen - (rp[i + 1] - rp[i])]++] = (int) i;
 	}
 	std::vector<int64_t> slice_ptr((size_t) num_slices + 1, 0);
-	#pragma omp parallel for
+	#pragma omp parallel for num_threads(spmv::host_threads())
 	for (long sl = 0; sl < num_slices; sl++)
 	{
 		long width = 0;
@@ -223,7 +223,7 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 	const int64_t nnz_ext = slice_ptr[num_slices];
 	std::vector<int> col((size_t) std::max<int64_t>(nnz_ext, 1));
 	std::vector<double> val((size_t) std::max<int64_t>(nnz_ext, 1));
-	#pragma omp parallel for schedule(dynamic, 64)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 64)
 	for (long sl = 0; sl < num_slices; sl++)
 	{
 		const int64_t base = slice_ptr[sl];
@@ -286,7 +286,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 	const long num_slices = (m + C - 1) / C;
 	std::vector<int> row_of_sorted(std::max<long>(m, 1));
 	const long num_windows = (m + sigma - 1) / sigma;
-	#pragma omp parallel for schedule(dynamic, 4)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4)
 	for (long w = 0; w < num_windows; w++)
 	{
 		long s = w * sigma, e = std::min(m, s + sigma);
@@ -304,7 +304,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 	// pass 1: width and mode of every slice
 	std::vector<int64_t> val_ptr((size_t) num_slices + 1, 0), idx_ptr((size_t) num_slices + 1, 0);
 	std::vector<unsigned char> mode((size_t) std::max<long>(num_slices, 1), 4);
-	#pragma omp parallel for schedule(dynamic, 64)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 64)
 	for (long sl = 0; sl < num_slices; sl++)
 	{
 		long width = 0;
@@ -348,7 +348,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 	std::vector<double> val((size_t) std::max<int64_t>(nnz_ext, 1));
 	std::vector<unsigned char> idx((size_t) std::max<int64_t>(idx_bytes, 16) + 1024, 0);
 	std::vector<int64_t> desc(2 * ((size_t) num_slices + 1), 0);
-	#pragma omp parallel for schedule(dynamic, 64)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 64)
 	for (long sl = 0; sl < num_slices; sl++)
 	{
 		const int64_t vb = val_ptr[sl];
@@ -559,7 +559,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 		l_rp.assign((size_t) lm + 1, 0);
 		const long c0 = o.col_begin, c1 = o.col_end;
 		const bool inside = o.col_filter_mode == 1;
-		#pragma omp parallel for
+		#pragma omp parallel for num_threads(spmv::host_threads())
 		for (long i = 0; i < lm; i++)
 		{
 			int cnt = 0;
@@ -578,7 +578,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 		lnnz = l_rp[lm];
 		l_ci.resize((size_t) std::max<long>(lnnz, 1));
 		l_va.resize((size_t) std::max<long>(lnnz, 1));
-		#pragma omp parallel for
+		#pragma omp parallel for num_threads(spmv::host_threads())
 		for (long i = 0; i < lm; i++)
 		{
 			long k = l_rp[i];
@@ -605,11 +605,11 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 	// full validation before anything reaches a kernel: an out-of-range index would be an out-of-bounds device read
 	{
 		long bad_col = -1, bad_row = -1;
-		#pragma omp parallel for reduction(max : bad_col)
+		#pragma omp parallel for num_threads(spmv::host_threads()) reduction(max : bad_col)
 		for (long j = 0; j < lnnz; j++)
 			if (ci[j] < 0 || ci[j] >= n)
 				bad_col = std::max(bad_col, j);
-		#pragma omp parallel for reduction(max : bad_row)
+		#pragma omp parallel for num_threads(spmv::host_threads()) reduction(max : bad_row)
 		for (long i = 0; i < lm; i++)
 			if (rp[i + 1] < rp[i])
 				bad_row = std::max(bad_row, i);
@@ -690,7 +690,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 						{
 							const long cap = mode == 3 ? csr_stream_d_cap(R) : csr_stream_t_cap(R);
 							long over = 0, blocks = (lm + R - 1) / R;
-							#pragma omp parallel for reduction(+ : over)
+							#pragma omp parallel for num_threads(spmv::host_threads()) reduction(+ : over)
 							for (long b = 0; b < blocks; b++)
 								over += (rp[std::min(lm, (b + 1) * R)] - rp[b * R]) > cap;
 							if (over * 200 <= blocks)

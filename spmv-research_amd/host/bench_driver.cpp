@@ -25,6 +25,7 @@
 
 #include "spmv_kernel.h"
 #include "spmv_host.h"
+#include "../csrc/host_threads.hpp"
 
 static double
 now()
@@ -54,7 +55,7 @@ check_accuracy(char * buf, long buf_n, const INT_T * ia, const INT_T * ja, const
 {
 	const __float128 epsilon = (sizeof(ValueType) == 8) ? (__float128) 1e-10 : (__float128) 1e-7;
 	std::vector<__float128> gold((size_t) std::max<long>(m, 1));
-	#pragma omp parallel for
+	#pragma omp parallel for num_threads(spmv::host_threads())
 	for (long i = 0; i < m; i++)
 	{
 		__float128 sum = 0, comp = 0;
@@ -102,7 +103,7 @@ check_accuracy(char * buf, long buf_n, const INT_T * ia, const INT_T * ja, const
 int
 main(int argc, char ** argv)
 {
-	int num_threads = omp_get_max_threads();
+	int num_threads = spmv::host_threads();
 	printf("max threads %d\n", num_threads);
 	if (argc == 1)
 	{

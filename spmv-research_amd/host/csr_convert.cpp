@@ -27,7 +27,7 @@ coo_to_csr(const int32_t * R, const int32_t * C, const double * V, long m, long 
 			return 1;
 		}
 	std::vector<int32_t> cnt((size_t) m + 1, 0);
-	#pragma omp parallel for
+	#pragma omp parallel for num_threads(spmv::host_threads())
 	for (long j = 0; j < nnz; j++)
 		__atomic_fetch_add(&cnt[R[j]], 1, __ATOMIC_RELAXED);
 	row_ptr[0] = 0;
@@ -36,13 +36,13 @@ coo_to_csr(const int32_t * R, const int32_t * C, const double * V, long m, long 
 	// scatter (order inside a row arbitrary), remembering the input position so that the per-row sort is total
 	std::vector<int32_t> fill(row_ptr, row_ptr + m);
 	std::vector<int32_t> src((size_t) std::max<long>(nnz, 1));
-	#pragma omp parallel for
+	#pragma omp parallel for num_threads(spmv::host_threads())
 	for (long j = 0; j < nnz; j++)
 	{
 		int32_t pos = __atomic_fetch_add(&fill[R[j]], 1, __ATOMIC_RELAXED);
 		src[pos] = (int32_t) j;
 	}
-	#pragma omp parallel
+	#pragma omp parallel num_threads(spmv::host_threads())
 	{
 		std::vector<std::pair<int32_t, int32_t>> key;
 		#pragma omp for schedule(dynamic, 1024)
@@ -72,7 +72,7 @@ csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, d
 	double sum_bw = 0, sum_neigh = 0, sum_sim = 0, sum_sq = 0;
 	long nonempty = 0, maxlen = 0;
 	const double avg = m > 0 ? (double) nnz / m : 0;
-	#pragma omp parallel for reduction(+ : sum_bw, sum_neigh, sum_sim, sum_sq, nonempty) reduction(max : maxlen) schedule(dynamic, 4096)
+	#pragma omp parallel for num_threads(spmv::host_threads()) reduction(+ : sum_bw, sum_neigh, sum_sim, sum_sq, nonempty) reduction(max : maxlen) schedule(dynamic, 4096)
 	for (long i = 0; i < m; i++)
 	{
 		const long s = row_ptr[i], e = row_ptr[i + 1], d = e - s;

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/spmv_host.h"
+#include "../csrc/host_threads.hpp"
 
 namespace spmv_host {
 

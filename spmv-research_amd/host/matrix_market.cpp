@@ -247,7 +247,7 @@ mtx_read(const char * filename, spmv_host_coo * out)
 
 		// ---- split the data region into chunks at line boundaries, count non-empty lines per chunk
 		const char * data = p;
-		const int T = omp_get_max_threads();
+		const int T = spmv::host_threads();
 		std::vector<const char *> cs(T + 1);
 		for (int t = 0; t <= T; t++)
 		{

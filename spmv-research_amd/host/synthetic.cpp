@@ -128,7 +128,7 @@ gen_twin(long m, long n, double avg, double std, double bw_scaled, double skew, 
 		return 1;
 	}
 	std::vector<long> len((size_t) m);
-	#pragma omp parallel for schedule(static, 4096)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 4096)
 	for (long i = 0; i < m; i++)
 	{
 		Rng g(seed, 2 * (uint64_t) i);
@@ -170,7 +170,7 @@ gen_twin(long m, long n, double avg, double std, double bw_scaled, double skew, 
 	const double p_crs = std::min(std::max(crs, 0.0), 0.98);
 	// rows are generated in blocks so that "previous row" is available without a serial dependency across blocks
 	const long BLK = 256;
-	#pragma omp parallel
+	#pragma omp parallel num_threads(spmv::host_threads())
 	{
 		std::vector<int32_t> cols, prev;
 		#pragma omp for schedule(dynamic, 16)
@@ -312,7 +312,7 @@ gen_kkt_row_ptr(long N, int32_t * row_ptr, long * m_out, long * nnz_out)
 		*m_out = m;
 	if (!row_ptr)
 		return 0;
-	#pragma omp parallel for schedule(static, 8192)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 8192)
 	for (long i = 0; i < m; i++)
 		row_ptr[i + 1] = kkt_row_len(G, i);
 	long acc = 0;
@@ -348,7 +348,7 @@ gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out)
 	}
 	const long lm = r1 - r0;
 	std::vector<int32_t> len((size_t) std::max<long>(lm, 1));
-	#pragma omp parallel for schedule(static, 8192)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 8192)
 	for (long i = 0; i < lm; i++)
 		len[i] = kkt_row_len(G, r0 + i);
 	long nnz = 0;
@@ -364,7 +364,7 @@ gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out)
 	out->row_ptr[0] = 0;
 	for (long i = 0; i < lm; i++)
 		out->row_ptr[i + 1] = out->row_ptr[i] + len[i];
-	#pragma omp parallel for schedule(static, 8192)
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 8192)
 	for (long li = 0; li < lm; li++)
 	{
 		const long i = r0 + li;
@@ -408,7 +408,7 @@ int
 remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, long padded)
 {
 	long bad = 0;
-	#pragma omp parallel for reduction(+ : bad)
+	#pragma omp parallel for num_threads(spmv::host_threads()) reduction(+ : bad)
 	for (long j = 0; j < nnz; j++)
 	{
 		long c = col_idx[j];
@@ -446,7 +446,7 @@ column_ranges(const int32_t * col_idx, long nnz, long padded, long parts, long *
 		hi[q] = 0;
 	}
 	int bad = 0;
-	#pragma omp parallel
+	#pragma omp parallel num_threads(spmv::host_threads())
 	{
 		std::vector<long> tlo((size_t) parts, padded), thi((size_t) parts, 0);
 		#pragma omp for nowait

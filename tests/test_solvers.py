@@ -168,9 +168,9 @@ def test_gpu_pcg_matches_oracle(oracle, name, fmt):
     assert got["error"] == pytest.approx(true_err, rel=1e-3, abs=1e-13 * np.linalg.norm(b))
     assert got["error"] == got["error_best"], "same kernels on the same vector: bit-equal"
     # launches: r0, one per loop body, the explicit checks, the final residual; the host sees the break flag with a lag of
-    # up to two polling windows, and the bodies enqueued meanwhile are predicated off on the device but still counted
+    # up to three polling windows, and the bodies enqueued meanwhile are predicated off on the device but still counted
     base = 1 + got["iterations"] + (got["iterations"] - 1) // 100 + 1
-    assert base <= got["spmv_calls"] <= base + 2 * 32 + 1
+    assert base <= got["spmv_calls"] <= base + 3 * 32 + 1
 
 
 @pytest.mark.gpu
