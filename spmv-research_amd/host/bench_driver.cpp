@@ -7,6 +7,11 @@
 //                     when GPU_KERNEL=1), per-call CLOCK_MONOTONIC_RAW timing until >= 64 loops and >= 2.0 s,
 //                     min/median/max, the _Float128 Kahan gold check, one CSV row on stderr with the reference's columns.
 //   * --twin NAME [scale] -> same, on a synthetic twin of a BASELINE.json matrix (our generator).
+//   * --cg | --bicgstab as FIRST argument -> the solver drivers instead (bench_cg.cpp / bench_bicg.cpp bench()+compute()):
+//                     b from <matrix>_b.mtx when that file exists, else all ones (bench_cg.cpp:497-523); one solve and one
+//                     CSV row (the reference's solver columns) per entry of CG_MAX_NUM_ITERS (space separated,
+//                     bench_cg.cpp:527-553; the reference exits when it is unset, here it defaults to "1000"); the solve
+//                     is the device-resident spmv_mi355x_pcg / spmv_mi355x_pbicgstab of the C ABI.
 // Environment variables of the reference are honoured when set (GPU_KERNEL, CLEAR_CACHES is N/A on the GPU, PROGG);
 // unlike the reference they may be absent (it dereferences getenv() unchecked: SURVEY §5).
 // Deliberate differences, both reported: GFLOPS uses the TRUE stored nnz (2*nnz/t; the reference multiplies general
@@ -19,13 +24,17 @@
 #include <float.h>
 #include <time.h>
 #include <algorithm>
+#include <string>
 #include <vector>
 #include <omp.h>
 #include <quadmath.h>
 
 #include "spmv_kernel.h"
 #include "spmv_host.h"
+#include "spmv_mi355x.h"
 #include "../csrc/host_threads.hpp"
+
+extern "C" spmv_mi355x_matrix * spmv_mi355x_handle_of(struct Matrix_Format * MF);      // spmv_kernel_mi355x.cpp
 
 static double
 now()
@@ -41,6 +50,10 @@ env_int(const char * name, int dflt)
 	const char * s = getenv(name);
 	return (s && *s) ? atoi(s) : dflt;
 }
+
+static const char * SOLVER_LABELS =      // bench_cg.cpp:423-440
+	"matrix_name,num_threads,csr_m,csr_n,csr_nnz,time,error,num_iterations,csr_mem_footprint,W_avg,J_estimated,"
+	"format_name,m,n,nnz,mem_footprint,mem_ratio";
 
 static const char * LABELS =
 	"matrix_name,num_threads,csr_m,csr_n,csr_nnz,symmetry,time,time_iter_min,time_iter_median,time_iter_max,gflops,"
@@ -105,9 +118,16 @@ main(int argc, char ** argv)
 {
 	int num_threads = spmv::host_threads();
 	printf("max threads %d\n", num_threads);
+	int solver = 0;                               // 0 = SpMV protocol, 1 = CG, 2 = BiCGSTAB
+	if (argc > 1 && (!strcmp(argv[1], "--cg") || !strcmp(argv[1], "--bicgstab")))
+	{
+		solver = !strcmp(argv[1], "--cg") ? 1 : 2;
+		argv++;
+		argc--;
+	}
 	if (argc == 1)
 	{
-		fprintf(stderr, "%s\n", LABELS);
+		fprintf(stderr, "%s\n", solver ? SOLVER_LABELS : LABELS);
 		return 0;
 	}
 
@@ -182,6 +202,74 @@ main(int argc, char ** argv)
 		std::fill(ia.begin(), ia.end(), -1);
 		std::fill(ja.begin(), ja.end(), -1);
 		ia.swap(ia2); ja.swap(ja2); a_ref.swap(a2);
+	}
+
+	if (solver)
+	{
+		if (m != n)
+		{
+			fprintf(stderr, "the matrix must be square\n");               // bench_cg.cpp:487-488
+			return 1;
+		}
+		// b: <matrix>_b.mtx (an n x 1 matrix) when it exists, else ones (bench_cg.cpp:497-523)
+		std::vector<ValueType> b((size_t) std::max<long>(n, 1), (ValueType) 1.0), x_out((size_t) std::max<long>(n, 1));
+		if (strcmp(argv[1], "--twin"))
+		{
+			std::string file_b(argv[1]);
+			if (file_b.size() > 4)
+				file_b = file_b.substr(0, file_b.size() - 4) + "_b.mtx";
+			printf("%s\n", file_b.c_str());
+			if (FILE * f = fopen(file_b.c_str(), "r"))
+			{
+				fclose(f);
+				spmv_host_coo vb;
+				t = now();
+				if (spmv_host_mtx_read(file_b.c_str(), &vb) || vb.m != n || vb.n != 1)
+				{
+					fprintf(stderr, "%s: not an %ld x 1 Matrix Market file (%s)\n", file_b.c_str(), n, spmv_host_last_error());
+					return 1;
+				}
+				std::fill(b.begin(), b.end(), (ValueType) 0);
+				for (long j = 0; j < vb.nnz; j++)
+					b[vb.R[j]] = (ValueType) vb.V[j];
+				spmv_host_coo_free(&vb);
+				printf("read vector file time = %lf\n", now() - t);
+			}
+		}
+		const char * list = getenv("CG_MAX_NUM_ITERS");
+		if (!list || !*list)
+			list = "1000";
+		spmv_mi355x_matrix * A = spmv_mi355x_handle_of(MF);
+		for (const char * p = list; *p;)
+		{
+			const long max_num_loops = atol(p);
+			spmv_mi355x_solver_info info;
+			memset(&info, 0, sizeof(info));
+			info.struct_size = sizeof(info);
+			int rc = solver == 1
+			         ? spmv_mi355x_pcg(A, ia.data(), ja.data(), a_ref.data(), b.data(), x_out.data(), max_num_loops, NULL, &info)
+			         : spmv_mi355x_pbicgstab(A, ia.data(), ja.data(), a_ref.data(), b.data(), x_out.data(), max_num_loops, NULL, &info);
+			if (rc)
+			{
+				fprintf(stderr, "%s\n", spmv_mi355x_last_error());
+				return 1;
+			}
+			printf("eps = %g eps_counter = %g\n", info.eps, info.eps_counter);
+			printf("error = %-12.4g\n", info.error);
+			char buf[10000];
+			long i = 0;
+			i += snprintf(buf + i, sizeof(buf) - i, "%s,%d,%lu,%lu,%lu", matrix_name, num_threads, m, n, nnz);
+			i += snprintf(buf + i, sizeof(buf) - i, ",%lf,%g,%ld", info.seconds, info.error, info.iterations);
+			i += snprintf(buf + i, sizeof(buf) - i, ",%lf,%lf,%lf", MF->csr_mem_footprint / (1024 * 1024), 0.0, 0.0);
+			i += snprintf(buf + i, sizeof(buf) - i, ",%s,%lu,%lu,%lu", MF->format_name, MF->m, MF->n, MF->nnz);
+			i += snprintf(buf + i, sizeof(buf) - i, ",%lf,%lf", MF->mem_footprint / (1024 * 1024), MF->mem_footprint / MF->csr_mem_footprint);
+			fprintf(stderr, "%s\n", buf);
+			while (*p && *p != ' ')                                      // next entry (bench_cg.cpp:541-552)
+				p++;
+			while (*p == ' ')
+				p++;
+		}
+		return 0;
 	}
 
 	// bench(): bench_spmv.cpp:598-609

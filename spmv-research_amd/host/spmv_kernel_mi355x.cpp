@@ -96,6 +96,14 @@ csr_to_format(INT_T * row_ptr, INT_T * col_ind, ValueTypeReference * values, lon
 	return mf;
 }
 
+// For bench_cg.cpp / bench_bicg.cpp: the device-resident solvers of the C ABI need the handle behind the Matrix_Format
+// (INTEGRATION.md §6). NULL when MF is not this backend's format cannot happen: one backend per executable.
+extern "C" spmv_mi355x_matrix *
+spmv_mi355x_handle_of(struct Matrix_Format * MF)
+{
+	return static_cast<MI355XFormat *>(MF)->handle;
+}
+
 int
 statistics_print_labels(__attribute__((unused)) char * buf, __attribute__((unused)) long buf_n)
 {

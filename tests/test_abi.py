@@ -71,3 +71,14 @@ def test_driver_prints_the_reference_csv_header():
             "gflops,csr_mem_footprint,W_avg,J_estimated,format_name,m,n,nnz,mem_footprint,mem_ratio,num_loops,"
             "spmv_mae,spmv_max_ae,spmv_mse,spmv_mape,spmv_smape,spmv_lnQ_error,spmv_mlare,spmv_gmare")
     assert r.stderr.strip() == want
+
+
+def test_driver_prints_the_reference_solver_csv_header():
+    import subprocess
+    exe = os.path.join(ROOT, "spmv-research_amd", "bin", "spmv_mi355x_bench")
+    want = ("matrix_name,num_threads,csr_m,csr_n,csr_nnz,time,error,num_iterations,csr_mem_footprint,W_avg,J_estimated,"
+            "format_name,m,n,nnz,mem_footprint,mem_ratio")                  # bench_cg.cpp:423-440 = bench_bicg.cpp:568-585
+    for flag in ("--cg", "--bicgstab"):
+        r = subprocess.run([exe, flag], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0
+        assert r.stderr.strip() == want

@@ -256,3 +256,31 @@ def test_gpu_solver_error_paths():
     MB = _matrix(B, "csr_vector")
     with pytest.raises(eng.SpmvError, match="square"):
         MB._solve(eng.lib().spmv_mi355x_pcg, np.zeros(7, np.int32), B.indices, B.data, np.ones(6), 10, False)
+
+
+@pytest.mark.gpu
+def test_gpu_driver_solver_mode(oracle, tmp_path):
+    """spmv_mi355x_bench --cg / --bicgstab: the reference's solver drivers (bench_cg.cpp bench()+compute()): b from
+    <matrix>_b.mtx, one CSV row per entry of CG_MAX_NUM_ITERS."""
+    import os
+    import subprocess
+    import scipy.io
+    from conftest import ROOT
+    A = laplace2d(24)
+    b = rhs(A)
+    scipy.io.mmwrite(str(tmp_path / "sys.mtx"), sp.coo_matrix(A), symmetry="general")
+    scipy.io.mmwrite(str(tmp_path / "sys_b.mtx"), sp.coo_matrix(b.reshape(-1, 1)))
+    exe = os.path.join(ROOT, "spmv-research_amd", "bin", "spmv_mi355x_bench")
+    for flag, fn in (("--cg", oracle.pcg), ("--bicgstab", oracle.pbicgstab)):
+        env = dict(os.environ, CG_MAX_NUM_ITERS="5 150", SPMV_MI355X_FORMAT="sell_c_sigma")
+        r = subprocess.run([exe, flag, str(tmp_path / "sys.mtx")], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        rows = [l.split(",") for l in r.stderr.strip().splitlines() if l.count(",") >= 16]
+        assert len(rows) == 2
+        for row, iters in zip(rows, (5, 150)):
+            want = fn(A.indptr, A.indices, A.data, b, iters)
+            assert abs(int(row[7]) - want["iterations"]) <= 2
+            true = np.linalg.norm(b - A @ want["x"])
+            assert float(row[6]) == pytest.approx(true, rel=1e-3, abs=1e-12 * np.linalg.norm(b))
+            assert row[11].startswith("MI355X_SELL") and int(row[2]) == A.shape[0] and int(row[4]) == A.nnz
+        assert "read vector file time" in r.stdout
