@@ -6,8 +6,9 @@
 //                 reference for the reordering kernels).
 //   csr_vector  : "one wavefront per row" (GPU_clean/spmv_subkernel_csr_rocm_vector.cpp:5-54; CPU analogue
 //                 csr_vec.cpp:182-213), generalised to G = 2..64 lanes per row so short rows do not idle a wave64.
-//                 Lane l of a group accumulates elements l, l+G, ... (coalesced 8/4-byte streams of val/col), then a
-//                 fixed xor-butterfly over the group gives the row sum: no LDS, no atomics, every y[i] written once.
+//                 Lane l of a group accumulates elements l, l+G, ... (coalesced 8/4-byte streams of val/col) in four
+//                 interleaved partial sums, then a fixed xor-butterfly over the group gives the row sum: no LDS, no
+//                 atomics, every y[i] written once, same bits from run to run.
 //
 // HBM-bound: per non-zero sizeof(V)+4 bytes streamed, x gathered through L2 / Infinity Cache.
 
@@ -36,38 +37,66 @@ csr_scalar_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col
 	y[row] = beta ? y[row] + sum : sum;
 }
 
+// Software-pipelined: a lane owns elements lane, lane+G, ... of its row and handles them in batches of U. The (col, val)
+// loads of batch b+1 are issued BEFORE the x gathers of batch b are consumed, so a row costs about one memory round trip
+// per batch instead of two (index -> gather are dependent). On the cache-resident matrices (cant: 62 k rows x 64) the
+// whole grid is a single wave of workgroups and the kernel time IS that dependent-latency chain.
 template <typename T, int G, bool NT>
 __global__ __launch_bounds__(CSR_BLOCK) void
 csr_vector_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
 		const T * __restrict__ x, T * __restrict__ y, int m, int beta, XcdMap map)
 {
 	constexpr int ROWS_PER_BLOCK = CSR_BLOCK / G;
+	constexpr int U = 4;
 	unsigned tile = xcd_tile(blockIdx.x, map);
 	if (tile == NO_TILE)
 		return;
 	const int row = tile * ROWS_PER_BLOCK + threadIdx.x / G;
 	const int lane = threadIdx.x % G;
-	T sum = 0;
+	T acc[U];
+	#pragma unroll
+	for (int u = 0; u < U; u++)
+		acc[u] = 0;
 	if (row < m)
 	{
 		const int j_s = row_ptr[row];
 		const int j_e = row_ptr[row + 1];
 		int j = j_s + lane;
-		// two independent accumulators: twice the loads in flight per lane for long rows
-		T sum2 = 0;
-		for (; j + G < j_e; j += 2 * G)
+		int c[U];
+		T v[U];
+		#pragma unroll
+		for (int u = 0; u < U; u++)
 		{
-			const int c0 = ld_stream<NT>(col + j);
-			const int c1 = ld_stream<NT>(col + j + G);
-			const T v0 = ld_stream<NT>(val + j);
-			const T v1 = ld_stream<NT>(val + j + G);
-			sum = fma_t<T>(v0, x[c0], sum);
-			sum2 = fma_t<T>(v1, x[c1], sum2);
+			const bool ok = j + u * G < j_e;
+			c[u] = ok ? ld_stream<NT>(col + j + u * G) : -1;
+			v[u] = ok ? ld_stream<NT>(val + j + u * G) : (T) 0;
 		}
-		if (j < j_e)
-			sum = fma_t<T>(ld_stream<NT>(val + j), x[ld_stream<NT>(col + j)], sum);
-		sum += sum2;
+		while (j < j_e)
+		{
+			T xv[U];
+			#pragma unroll
+			for (int u = 0; u < U; u++)
+				xv[u] = c[u] >= 0 ? x[c[u]] : (T) 0;
+			j += U * G;
+			int cn[U];
+			T vn[U];
+			#pragma unroll
+			for (int u = 0; u < U; u++)
+			{
+				const bool ok = j + u * G < j_e;
+				cn[u] = ok ? ld_stream<NT>(col + j + u * G) : -1;
+				vn[u] = ok ? ld_stream<NT>(val + j + u * G) : (T) 0;
+			}
+			#pragma unroll
+			for (int u = 0; u < U; u++)
+			{
+				acc[u] = c[u] >= 0 ? fma_t<T>(v[u], xv[u], acc[u]) : acc[u];
+				c[u] = cn[u];
+				v[u] = vn[u];
+			}
+		}
 	}
+	T sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 	sum = group_reduce_sum<T, G>(sum);
 	if (row < m && lane == 0)
 		y[row] = beta ? y[row] + sum : sum;
