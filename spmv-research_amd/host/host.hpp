@@ -16,6 +16,16 @@ void set_error(const char * fmt, ...);
 void partition_iterations(long num_workers, long worker_pos, long start, long end, long * s, long * e);
 void partition_prefix_sums(long num_workers, long worker_pos, const int32_t * sums, long N, long total_sum, long * s, long * e);
 
+// A file's bytes: either the mmap of the file itself or a malloc'ed buffer holding the decompressed / extracted text
+// (file_load.cpp; replaces lib/parallel_io.c:28-130 of the reference).
+struct FileBuf {
+	const char * data = nullptr;
+	size_t size = 0;
+	bool mapped = false;
+	void release();
+};
+int file_load(const char * path, FileBuf & out);
+
 int mtx_read(const char * filename, spmv_host_coo * out);
 int coo_to_csr(const int32_t * R, const int32_t * C, const double * V, long m, long n, long nnz,
 		int32_t * row_ptr, int32_t * col_idx, double * values);

@@ -136,28 +136,16 @@ int
 mtx_read(const char * filename, spmv_host_coo * out)
 {
 	memset(out, 0, sizeof(*out));
-	int fd = open(filename, O_RDONLY);
-	if (fd < 0)
-	{
-		set_error("cannot open '%s': %s", filename, strerror(errno));
+	FileBuf file;                                   // plain, .gz, .zst, .tar and combinations (file_load.cpp)
+	if (file_load(filename, file))
 		return 1;
-	}
-	struct stat st;
-	fstat(fd, &st);
-	const size_t N = (size_t) st.st_size;
+	const size_t N = file.size;
 	if (N == 0)
 	{
-		close(fd);
 		set_error("Error parsing MARKET matrix '%s': empty file", filename);
 		return 1;
 	}
-	const char * buf = (const char *) mmap(NULL, N, PROT_READ, MAP_PRIVATE, fd, 0);
-	close(fd);
-	if (buf == MAP_FAILED)
-	{
-		set_error("mmap of '%s' failed: %s", filename, strerror(errno));
-		return 1;
-	}
+	const char * buf = file.data;
 	const char * end = buf + N;
 	int rc = 1;
 	int32_t * R = NULL, * C = NULL;
@@ -371,7 +359,7 @@ mtx_read(const char * filename, spmv_host_coo * out)
 		V = NULL;
 		rc = 0;
 	} while (0);
-	munmap((void *) buf, N);
+	file.release();
 	free(R); free(C); free(V);
 	return rc;
 }

@@ -200,3 +200,83 @@ def test_mtx_writer_round_trip(H, tmp_path):
     np.testing.assert_array_equal(rp, A["row_ptr"])
     np.testing.assert_array_equal(ci, A["col_idx"])
     np.testing.assert_array_equal(va, A["values"])           # %.17g round-trips fp64 exactly
+
+
+# ---- compressed / archived inputs (reference: lib/parallel_io.c:28-130 shells out to zstdmt / tar) ----------
+
+def _zstd_compress(data, frames=1):
+    import ctypes as C
+    z = C.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+    out = b""
+    step = -(-len(data) // frames)
+    for i in range(0, len(data), step):
+        part = data[i:i + step]
+        buf = C.create_string_buffer(z.ZSTD_compressBound(len(part)))
+        n = z.ZSTD_compress(buf, len(buf), part, len(part), 3)
+        assert not z.ZSTD_isError(n)
+        out += buf.raw[:n]
+    return out
+
+
+@pytest.mark.parametrize("case", ["general_real", "symmetric_real", "pattern_general"])
+def test_reader_accepts_compressed_and_archived_inputs(case, tmp_path):
+    import gzip
+    import io
+    import tarfile
+    import spmv_host as H
+    from conftest import GOLDEN
+    src = os.path.join(GOLDEN, case + ".mtx")
+    text = open(src, "rb").read()
+    want = H.mtx_read(src)
+
+    def same(path):
+        got = H.mtx_read(str(path))
+        assert got[0] == want[0], path
+        for a, b in zip(got[1:], want[1:]):
+            assert np.array_equal(a, b), path
+
+    (tmp_path / "a.mtx.gz").write_bytes(gzip.compress(text))
+    same(tmp_path / "a.mtx.gz")
+    half = len(text) // 2                                           # two gzip members back to back (pigz / cat a.gz b.gz)
+    (tmp_path / "b.mtx.gz").write_bytes(gzip.compress(text[:half]) + gzip.compress(text[half:]))
+    same(tmp_path / "b.mtx.gz")
+    (tmp_path / "c.mtx.zst").write_bytes(_zstd_compress(text))
+    same(tmp_path / "c.mtx.zst")
+    (tmp_path / "d.mtx.zst").write_bytes(_zstd_compress(text, frames=3))
+    same(tmp_path / "d.mtx.zst")
+    # SuiteSparse layout: <name>.tar.gz holding <name>/<name>.mtx (a directory entry first)
+    bio = io.BytesIO()
+    with tarfile.open(fileobj=bio, mode="w") as tf:
+        d = tarfile.TarInfo("m")
+        d.type = tarfile.DIRTYPE
+        tf.addfile(d)
+        ti = tarfile.TarInfo("m/m.mtx")
+        ti.size = len(text)
+        tf.addfile(ti, io.BytesIO(text))
+    (tmp_path / "m.tar").write_bytes(bio.getvalue())
+    same(tmp_path / "m.tar")
+    (tmp_path / "m.tar.gz").write_bytes(gzip.compress(bio.getvalue()))
+    same(tmp_path / "m.tar.gz")
+    (tmp_path / "m.tgz").write_bytes(gzip.compress(bio.getvalue()))
+    same(tmp_path / "m.tgz")
+    # the reference sends .gz through zstdmt too, which sniffs the format: a gzip stream named .zst must still load
+    (tmp_path / "e.mtx.zst").write_bytes(gzip.compress(text))
+    same(tmp_path / "e.mtx.zst")
+
+
+def test_reader_reports_corrupt_compressed_input(tmp_path):
+    import gzip
+    import spmv_host as H
+    from conftest import GOLDEN
+    text = open(os.path.join(GOLDEN, "general_real.mtx"), "rb").read()
+    z = gzip.compress(text)
+    (tmp_path / "t.mtx.gz").write_bytes(z[:len(z) // 2])
+    with pytest.raises(Exception, match="corrupt or truncated"):
+        H.mtx_read(str(tmp_path / "t.mtx.gz"))
+    (tmp_path / "e.tar").write_bytes(b"\0" * 1024)
+    with pytest.raises(Exception, match="no regular file"):
+        H.mtx_read(str(tmp_path / "e.tar"))
