@@ -75,6 +75,8 @@ typedef struct {
 	int  col_filter_mode;   /* 0 = keep all, 1 = keep columns inside [col_begin,col_end), 2 = keep columns outside     */
 	int  sell_delta;        /* SELL with 64-row slices: column indices stored as one base per step + 8/16-bit deltas per lane
 	                           where they fit (lossless, bit-identical results): 0 = auto (on when sell_c = 64), 1 = on, 2 = off */
+	int  convert_on;        /* where the SELL delta layout is built from the CSR: 0 = auto (GPU), 1 = GPU (csrc/convert_sell.hip),
+	                           2 = host (OpenMP; kept as the checker — both produce the same bytes)                    */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */

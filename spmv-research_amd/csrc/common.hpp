@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "host_threads.hpp"
 
@@ -44,6 +45,19 @@ struct XcdMap {
 constexpr unsigned XCD_CHUNK_DEFAULT = 64;
 
 constexpr unsigned NO_TILE = 0xffffffffu;
+
+// tiles per chunk of the chunked order: SPMV_MI355X_XCD_CHUNK (a power of two) or the default; read at every create()
+inline unsigned
+xcd_chunk_setting()
+{
+	if (const char * e = getenv("SPMV_MI355X_XCD_CHUNK"))
+	{
+		const long v = atol(e);
+		if (v >= 1 && v <= (1 << 20) && (v & (v - 1)) == 0)
+			return (unsigned) v;
+	}
+	return XCD_CHUNK_DEFAULT;
+}
 
 __device__ __forceinline__ unsigned
 xcd_tile(unsigned bid, const XcdMap & mp)
@@ -85,7 +99,7 @@ xcd_map_uniform(unsigned ntiles, int remap)
 	XcdMap mp;
 	mp.ntiles = ntiles;
 	mp.remap = (unsigned) remap;
-	mp.chunk = XCD_CHUNK_DEFAULT;
+	mp.chunk = xcd_chunk_setting();
 	for (int k = 0; k <= NUM_XCD; k++)
 		mp.start[k] = (unsigned) ((unsigned long long) ntiles * k / NUM_XCD);
 	return mp;
@@ -101,7 +115,7 @@ xcd_map_balanced(const P * prefix, long num_units, long units_per_tile, int rema
 	const long ntiles = (num_units + units_per_tile - 1) / units_per_tile;
 	mp.ntiles = (unsigned) ntiles;
 	mp.remap = (unsigned) remap;
-	mp.chunk = XCD_CHUNK_DEFAULT;
+	mp.chunk = xcd_chunk_setting();
 	const double total = (double) (prefix[num_units] - prefix[0]);
 	mp.start[0] = 0;
 	for (int k = 1; k < NUM_XCD; k++)

@@ -1,0 +1,320 @@
+// CSR -> SELL-64-sigma-delta ON THE GPU.
+//
+// The reference converts on the host (sell_sorted.cpp:112-298, sellcs_format.c:137-200; the driver reports it as
+// "time convert to format", bench.cpp:600-603) and so did build_sell_delta() in spmv_mi355x.hip, which stays as the
+// checker: this path must produce the SAME bytes (tests/test_gpu_parity.py compares the two layouts).
+//   1. row lengths; stable sort of the rows of every sigma-window by length, descending (radix_sort.c:103-122 semantics):
+//      one segmented radix sort (hipCUB; radix sort is stable, so equal lengths keep their row order);
+//   2. one wave per 64-row slice: width (max length, padded to 4 steps) and the narrowest index encoding that holds every
+//      (step, lane) delta against the step's minimum column;
+//   3. exclusive scans -> value / index offsets of the slices;
+//   4. one wave per slice fills values (column-major, narrowed to the handle's precision), step bases and packed deltas.
+// The CSR arrays are uploaded once and freed afterwards; nothing but the slice offsets returns to the host (they feed the
+// XCD tile map).
+
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "launch.hpp"
+
+namespace spmv {
+
+constexpr int CV_BLOCK = 256;
+
+__global__ __launch_bounds__(CV_BLOCK) void
+row_length_kernel(const int * __restrict__ rp, int m, int * __restrict__ len, int * __restrict__ ids)
+{
+	const int i = blockIdx.x * CV_BLOCK + threadIdx.x;
+	if (i < m)
+	{
+		len[i] = rp[i + 1] - rp[i];
+		ids[i] = i;
+	}
+}
+
+__global__ __launch_bounds__(CV_BLOCK) void
+window_offsets_kernel(long m, long sigma, long num_windows, int * __restrict__ off)
+{
+	const long w = (long) blockIdx.x * CV_BLOCK + threadIdx.x;
+	if (w <= num_windows)
+		off[w] = (int) (w * sigma < m ? w * sigma : m);
+}
+
+__device__ __forceinline__ int
+wave_min_i(int v)
+{
+	for (int o = WAVE / 2; o > 0; o >>= 1)
+		v = min(v, __shfl_xor(v, o, WAVE));
+	return v;
+}
+
+__device__ __forceinline__ int
+wave_max_i(int v)
+{
+	for (int o = WAVE / 2; o > 0; o >>= 1)
+		v = max(v, __shfl_xor(v, o, WAVE));
+	return v;
+}
+
+__device__ __forceinline__ long
+group_bytes(int md)
+{
+	return md == 1 ? 272 : md == 2 ? 528 : 1024;
+}
+
+// pass 1: one wave per slice -> mode, number of value slots, number of index bytes
+__global__ __launch_bounds__(CV_BLOCK) void
+slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, const int * __restrict__ row_of_sorted, long m,
+		long num_slices, unsigned char * __restrict__ mode, int64_t * __restrict__ val_count, int64_t * __restrict__ idx_count)
+{
+	const long sl = ((long) blockIdx.x * CV_BLOCK + threadIdx.x) / WAVE;
+	const int lane = threadIdx.x % WAVE;
+	if (sl >= num_slices)
+		return;
+	const long i = sl * WAVE + lane;
+	int start = 0, len = 0;
+	if (i < m)
+	{
+		const int o = row_of_sorted[i];
+		start = rp[o];
+		len = rp[o + 1] - start;
+	}
+	const int width = (wave_max_i(len) + 3) / 4 * 4;
+	int maxdelta = 0;
+	for (int k = 0; k < width; k++)
+	{
+		const bool ok = k < len;
+		const int c = ok ? ci[start + k] : 0;
+		const int lo = wave_min_i(ok ? c : 0x7fffffff);
+		const int hi = wave_max_i(ok ? c : -1);
+		if (hi >= 0)
+			maxdelta = max(maxdelta, hi - lo);
+	}
+	if (lane == 0)
+	{
+		const int md = maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		mode[sl] = (unsigned char) md;
+		val_count[sl] = (int64_t) width * WAVE;
+		idx_count[sl] = (int64_t) (width / 4) * group_bytes(md);
+	}
+}
+
+// pass 2: one wave per slice fills its values, bases and deltas (layout: kernels_sell.hip)
+template <typename T>
+__global__ __launch_bounds__(CV_BLOCK) void
+slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, const double * __restrict__ va,
+		const int * __restrict__ row_of_sorted, long m, long num_slices, const unsigned char * __restrict__ mode,
+		const int64_t * __restrict__ val_ptr, const int64_t * __restrict__ idx_ptr, T * __restrict__ val,
+		unsigned char * __restrict__ idx, int64_t * __restrict__ desc)
+{
+	const long sl = ((long) blockIdx.x * CV_BLOCK + threadIdx.x) / WAVE;
+	const int lane = threadIdx.x % WAVE;
+	if (sl > num_slices)
+		return;
+	if (sl == num_slices)                              // terminator entry
+	{
+		if (lane == 0)
+		{
+			desc[2 * sl] = val_ptr[sl];
+			desc[2 * sl + 1] = idx_ptr[sl] | 4;
+		}
+		return;
+	}
+	const int64_t vb = val_ptr[sl];
+	const int width = (int) ((val_ptr[sl + 1] - vb) / WAVE);
+	const int md = mode[sl];
+	unsigned char * ib = idx + idx_ptr[sl];
+	if (lane == 0)
+	{
+		desc[2 * sl] = vb;
+		desc[2 * sl + 1] = idx_ptr[sl] | md;
+	}
+	const long i = sl * WAVE + lane;
+	int start = 0, len = 0;
+	if (i < m)
+	{
+		const int o = row_of_sorted[i];
+		start = rp[o];
+		len = rp[o + 1] - start;
+	}
+	const long gbytes = group_bytes(md);
+	for (int g = 0; g < width / 4; g++)
+	{
+		unsigned char * gp = ib + g * gbytes;
+		unsigned d[4];
+		#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const int k = g * 4 + u;
+			const bool ok = k < len;
+			int c = ok ? ci[start + k] : 0x7fffffff;
+			int base = wave_min_i(c);
+			if (base == 0x7fffffff)
+				base = 0;                              // a step that is padding for every lane
+			if (!ok)
+				c = base;                              // padding: value 0 times a column some lane really uses
+			val[vb + (long) k * WAVE + lane] = ok ? (T) va[start + k] : (T) 0;
+			if (md != 4)
+			{
+				if (lane == 0)
+					reinterpret_cast<int *>(gp)[u] = base;
+				d[u] = (unsigned) (c - base);
+			}
+			else
+				reinterpret_cast<int *>(gp)[u * WAVE + lane] = c;
+		}
+		if (md == 1)
+			reinterpret_cast<unsigned *>(gp + 16)[lane] = d[0] | d[1] << 8 | d[2] << 16 | d[3] << 24;
+		else if (md == 2)
+		{
+			uint2 pk;
+			pk.x = d[0] | d[1] << 16;
+			pk.y = d[2] | d[3] << 16;
+			reinterpret_cast<uint2 *>(gp + 16)[lane] = pk;
+		}
+	}
+}
+
+struct Scratch {
+	std::vector<void *> ptrs;
+	~Scratch()
+	{
+		for (void * p : ptrs)
+			(void) hipFree(p);
+	}
+	template <typename P>
+	int get(P ** out, size_t bytes)
+	{
+		void * p = nullptr;
+		HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+		ptrs.push_back(p);
+		*out = (P *) p;
+		return 0;
+	}
+};
+
+// Outputs (device, owned by the caller on success): row_of_sorted[m], desc[2*(slices+1)], idx[idx_bytes+1024], val[nnz_ext
+// + STREAM_SLACK] of the handle's precision. Host outputs: val_ptr (slices+1, for the tile map), mode counts, sizes.
+int
+sell_delta_convert_device(bool f32, long m, long nnz, long sigma, const int * rp_host, const int * ci_host, const double * va_host,
+		int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
+		std::vector<int64_t> & val_ptr_host, long mode_counts[3], int64_t * nnz_ext_out, int64_t * idx_bytes_out)
+{
+	const long num_slices = (m + WAVE - 1) / WAVE;
+	const long num_windows = (m + sigma - 1) / sigma;
+	Scratch tmp;
+	int * rp, * ci, * len, * len_sorted, * ids, * win_off;
+	double * va;
+	if (tmp.get(&rp, (size_t) (m + 1) * 4) || tmp.get(&ci, (size_t) nnz * 4) || tmp.get(&va, (size_t) nnz * 8) ||
+	    tmp.get(&len, (size_t) m * 4) || tmp.get(&len_sorted, (size_t) m * 4) || tmp.get(&ids, (size_t) m * 4) ||
+	    tmp.get(&win_off, (size_t) (num_windows + 1) * 4))
+		return 1;
+	if (rp_host[0] != 0)
+	{
+		set_error("sell_delta_convert_device: row_ptr must start at 0");
+		return 1;
+	}
+	HIP_TRY(hipMemcpy(rp, rp_host, (size_t) (m + 1) * 4, hipMemcpyHostToDevice));
+	if (nnz)
+	{
+		HIP_TRY(hipMemcpy(ci, ci_host, (size_t) nnz * 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(va, va_host, (size_t) nnz * 8, hipMemcpyHostToDevice));
+	}
+	int * row_of_sorted = nullptr;
+	HIP_TRY(hipMalloc(&row_of_sorted, (size_t) std::max<long>(m, 1) * 4 + STREAM_SLACK * 4));
+	Scratch out_guard;                                 // frees the outputs if anything below fails
+	out_guard.ptrs.push_back(row_of_sorted);
+	HIP_TRY(hipMemset(row_of_sorted, 0, (size_t) std::max<long>(m, 1) * 4 + STREAM_SLACK * 4));
+
+	// 1. sigma-window sort by length, descending, stable
+	if (m > 0)
+	{
+		hipLaunchKernelGGL(row_length_kernel, dim3((unsigned) ((m + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0, rp, (int) m, len, ids);
+		hipLaunchKernelGGL(window_offsets_kernel, dim3((unsigned) ((num_windows + 1 + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0,
+				m, sigma, num_windows, win_off);
+		HIP_TRY(hipGetLastError());
+		size_t bytes = 0;
+		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, bytes, len, len_sorted, ids, row_of_sorted, (int) m,
+				(int) num_windows, win_off, win_off + 1, 0, 32, (hipStream_t) 0));
+		void * sort_tmp;
+		if (tmp.get(&sort_tmp, bytes))
+			return 1;
+		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(sort_tmp, bytes, len, len_sorted, ids, row_of_sorted, (int) m,
+				(int) num_windows, win_off, win_off + 1, 0, 32, (hipStream_t) 0));
+	}
+
+	// 2. slice shapes   3. offsets
+	unsigned char * mode;
+	int64_t * val_count, * idx_count, * val_ptr, * idx_ptr;
+	if (tmp.get(&mode, (size_t) num_slices + 1) || tmp.get(&val_count, (size_t) (num_slices + 1) * 8) ||
+	    tmp.get(&idx_count, (size_t) (num_slices + 1) * 8) || tmp.get(&val_ptr, (size_t) (num_slices + 1) * 8) ||
+	    tmp.get(&idx_ptr, (size_t) (num_slices + 1) * 8))
+		return 1;
+	HIP_TRY(hipMemset(val_count, 0, (size_t) (num_slices + 1) * 8));
+	HIP_TRY(hipMemset(idx_count, 0, (size_t) (num_slices + 1) * 8));
+	const unsigned slice_grid = (unsigned) (((num_slices + 1) * WAVE + CV_BLOCK - 1) / CV_BLOCK);
+	if (num_slices > 0)
+	{
+		hipLaunchKernelGGL(slice_shape_kernel, dim3(slice_grid), dim3(CV_BLOCK), 0, 0, rp, ci, row_of_sorted, m, num_slices, mode,
+				val_count, idx_count);
+		HIP_TRY(hipGetLastError());
+	}
+	{
+		size_t bytes = 0;
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, val_count, val_ptr, (int) (num_slices + 1), (hipStream_t) 0));
+		void * scan_tmp;
+		if (tmp.get(&scan_tmp, bytes))
+			return 1;
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, bytes, val_count, val_ptr, (int) (num_slices + 1), (hipStream_t) 0));
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, bytes, idx_count, idx_ptr, (int) (num_slices + 1), (hipStream_t) 0));
+	}
+	val_ptr_host.assign((size_t) num_slices + 1, 0);
+	HIP_TRY(hipMemcpy(val_ptr_host.data(), val_ptr, (size_t) (num_slices + 1) * 8, hipMemcpyDeviceToHost));
+	int64_t idx_bytes = 0;
+	HIP_TRY(hipMemcpy(&idx_bytes, idx_ptr + num_slices, 8, hipMemcpyDeviceToHost));
+	const int64_t nnz_ext = val_ptr_host[num_slices];
+	{
+		std::vector<unsigned char> mode_host((size_t) std::max<long>(num_slices, 1));
+		if (num_slices)
+			HIP_TRY(hipMemcpy(mode_host.data(), mode, (size_t) num_slices, hipMemcpyDeviceToHost));
+		mode_counts[0] = mode_counts[1] = mode_counts[2] = 0;
+		for (long sl = 0; sl < num_slices; sl++)
+			mode_counts[mode_host[sl] == 1 ? 0 : mode_host[sl] == 2 ? 1 : 2]++;
+	}
+
+	// 4. fill
+	const size_t vbytes = f32 ? 4 : 8;
+	void * val = nullptr;
+	unsigned char * idx = nullptr;
+	int64_t * desc = nullptr;
+	const size_t idx_alloc = (size_t) std::max<int64_t>(idx_bytes, 16) + 1024;
+	HIP_TRY(hipMalloc(&val, ((size_t) nnz_ext + STREAM_SLACK) * vbytes));
+	out_guard.ptrs.push_back(val);
+	HIP_TRY(hipMalloc(&idx, idx_alloc));
+	out_guard.ptrs.push_back(idx);
+	HIP_TRY(hipMalloc(&desc, 2 * ((size_t) num_slices + 1) * 8));
+	out_guard.ptrs.push_back(desc);
+	HIP_TRY(hipMemset((char *) val + (size_t) nnz_ext * vbytes, 0, STREAM_SLACK * vbytes));
+	HIP_TRY(hipMemset(idx + (idx_alloc - 1040), 0, 1040));     // the tail the kernels may read past the last group
+	if (idx_bytes < 16)
+		HIP_TRY(hipMemset(idx, 0, idx_alloc));
+	if (f32)
+		hipLaunchKernelGGL((slice_fill_kernel<float>), dim3(slice_grid), dim3(CV_BLOCK), 0, 0, rp, ci, va, row_of_sorted, m, num_slices,
+				mode, val_ptr, idx_ptr, (float *) val, idx, desc);
+	else
+		hipLaunchKernelGGL((slice_fill_kernel<double>), dim3(slice_grid), dim3(CV_BLOCK), 0, 0, rp, ci, va, row_of_sorted, m, num_slices,
+				mode, val_ptr, idx_ptr, (double *) val, idx, desc);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipDeviceSynchronize());
+	out_guard.ptrs.clear();                            // success: ownership moves to the caller
+	*d_row_of_sorted_out = row_of_sorted;
+	*d_desc_out = desc;
+	*d_idx_out = idx;
+	*d_val_out = val;
+	*nnz_ext_out = nnz_ext;
+	*idx_bytes_out = idx_bytes;
+	return 0;
+}
+
+}  // namespace spmv

@@ -2,6 +2,8 @@
 // All launchers enqueue on `stream` and return 0 / 1 (error text via spmv::set_error). `f32` selects float.
 #pragma once
 
+#include <vector>
+
 #include "common.hpp"
 
 namespace spmv {
@@ -55,6 +57,11 @@ int launch_sell(bool f32, int C, const int64_t * slice_ptr, const int * col, con
 // SELL-64-sigma with delta-compressed column indices (desc: 2 int64 per slice + terminator, idx: byte stream)
 int launch_sell_delta(bool f32, int waves_per_slice, const int64_t * desc, const unsigned char * idx, const void * val, const int * row_of_sorted,
 		const void * x, void * y, int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+
+// CSR -> SELL-64-sigma-delta on the GPU (convert_sell.hip); outputs are device arrays owned by the caller
+int sell_delta_convert_device(bool f32, long m, long nnz, long sigma, const int * rp_host, const int * ci_host, const double * va_host,
+		int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
+		std::vector<int64_t> & val_ptr_host, long mode_counts[3], int64_t * nnz_ext_out, int64_t * idx_bytes_out);
 
 // ---- COO (kernels_coo.hip)
 int coo_wave_items(int items_per_lane);                                // entries per wavefront

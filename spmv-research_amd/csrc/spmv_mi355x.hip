@@ -57,6 +57,7 @@ struct spmv_mi355x_matrix {
 	int64_t * d_slice_ptr = nullptr;
 	int * d_row_of_sorted = nullptr;
 	bool sell_delta = false;               // delta-compressed column indices (C = 64 only)
+	bool convert_on_device = true;         // build the delta layout on the GPU (convert_sell.hip) or on the host
 	int sell_split = 1;                    // waves sharing one slice (delta format): 1, 2 or 4
 	int64_t * d_sell_desc = nullptr;
 	unsigned char * d_sell_idx = nullptr;
@@ -284,6 +285,23 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 	constexpr int C = 64;
 	const long sigma = A->sell_sigma;
 	const long num_slices = (m + C - 1) / C;
+	if (A->convert_on_device)
+	{
+		std::vector<int64_t> val_ptr;
+		int64_t nnz_ext = 0, idx_bytes = 0;
+		void * d_val = nullptr;
+		if (sell_delta_convert_device(A->f32, m, A->nnz, sigma, rp, ci, va, &A->d_row_of_sorted, &A->d_sell_desc, &A->d_sell_idx,
+				&d_val, val_ptr, A->sell_mode_slices, &nnz_ext, &idx_bytes))
+			return 1;
+		A->d_val = d_val;
+		A->sell_slices = num_slices;
+		A->sell_nnz_ext = nnz_ext;
+		A->sell_idx_bytes = idx_bytes;
+		const long spt = sell_slices_per_tile() / A->sell_split;
+		A->cfg.map = xcd_map_balanced(val_ptr.data(), num_slices, spt, resolve_remap(A->remap, (num_slices + spt - 1) / spt));
+		A->mem_footprint = (double) (num_slices + 1) * 16 + (double) nnz_ext * A->vbytes + (double) idx_bytes + (double) m * 4;
+		return 0;
+	}
 	std::vector<int> row_of_sorted(std::max<long>(m, 1));
 	const long num_windows = (m + sigma - 1) / sigma;
 	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4)
@@ -782,6 +800,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 			A->sell_c = C;
 			A->sell_sigma = sigma;
 			A->sell_delta = (C == 64) && (o.sell_delta != 2);      // 0 = auto (on for 64-row slices), 1 = on, 2 = off
+			A->convert_on_device = o.convert_on != 2 && !getenv("SPMV_MI355X_HOST_CONVERT");
 			{
 				// waves per slice: enough wavefronts to occupy 256 CUs several times over
 				const long slices = (lm + 63) / 64;

@@ -256,3 +256,72 @@ def test_create_rejects_bad_input(eng):
         eng.Matrix(rp, np.array([0, 1], np.int32), a, 2, 2, "csr_vector", lanes_per_row=3)
     with pytest.raises(eng.SpmvError):
         eng.Matrix(rp, np.array([0, 1], np.int32), a, 2, 2, "sell_c_sigma", sell_c=48)
+
+
+# ---- GPU-side CSR -> SELL-64-sigma-delta conversion (csrc/convert_sell.hip, §8 row f2) against the host builder -------------
+
+def _banded(rng, m, bw, per_row):
+    """columns within +-bw of the diagonal: 8-bit deltas when bw is small, 16-bit when it is a few thousand"""
+    rp = np.arange(m + 1, dtype=np.int64) * per_row
+    ci = np.empty(m * per_row, np.int32)
+    for i in range(m):
+        lo, hi = max(0, i - bw), min(m, i + bw + 1)
+        ci[i * per_row:(i + 1) * per_row] = np.sort(rng.choice(np.arange(lo, hi), per_row, replace=False))
+    return rp.astype(np.int32), ci, rng.uniform(-1, 1, m * per_row)
+
+
+CONVERT_CASES = ["banded8", "banded16", "powerlaw", "short", "regular_ragged", "one_row", "empty"]
+
+
+@pytest.mark.parametrize("name", CONVERT_CASES)
+def test_device_conversion_equals_host_conversion(eng, oracle, name):
+    rng = np.random.default_rng(MANIFEST["seed"] + 5)
+    if name == "banded8":
+        m = n = 5000
+        rp, ci, a = _banded(rng, m, 40, 9)
+    elif name == "banded16":
+        m = n = 6001
+        rp, ci, a = _banded(rng, m, 3000, 7)
+    elif name == "regular_ragged":
+        m, n = 4099, 257
+        rp, ci, a = synth(rng, m, n, "regular")
+    elif name == "one_row":
+        m, n = 1000, 70000
+        rp, ci, a = synth(rng, m, n, "one_row")
+    elif name == "empty":
+        m, n = 777, 555
+        rp, ci, a = synth(rng, m, n, "empty")
+    else:
+        m = n = 30000
+        rp, ci, a = synth(rng, m, n, name)
+    x = rng.uniform(-1, 1, n)
+    for dtype in (np.float64, np.float32):
+        for sigma in (64, 1024, 16384):
+            H = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=sigma, sell_split=1, convert_on=2)
+            D = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=sigma, sell_split=1, convert_on=1)
+            lh, ld = H.sell_layout(), D.sell_layout()
+            assert D.mem_footprint == H.mem_footprint and D.format_name == H.format_name
+            for k in ("num_slices", "nnz_ext", "C", "sigma"):
+                assert lh[k] == ld[k], k
+            for k in ("row_of_sorted", "slice_ptr", "col", "val"):
+                np.testing.assert_array_equal(ld[k], lh[k], err_msg=f"{name} sigma={sigma} {k}")
+            np.testing.assert_array_equal(D.spmv(x), H.spmv(x))
+            y_ref = oracle.csr_spmv(rp, ci, a, x, dtype, num_threads=1)
+            np.testing.assert_array_equal(D.spmv(x), y_ref)           # left-to-right FMA per row: bit-exact
+            H.close()
+            D.close()
+
+
+def test_device_conversion_on_golden_cases(eng):
+    for case in CASES:
+        info, z = load_case(case)
+        rp, ci, a = z["row_ptr"], z["col_idx"], z["values"]
+        m, n = info["m"], info["n"]
+        H = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", np.float64, sell_c=64, sell_delta=1, convert_on=2)
+        D = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", np.float64, sell_c=64, sell_delta=1, convert_on=1)
+        lh, ld = H.sell_layout(), D.sell_layout()
+        assert D.mem_footprint == H.mem_footprint, case
+        for k in ("row_of_sorted", "slice_ptr", "col", "val"):
+            np.testing.assert_array_equal(ld[k], lh[k], err_msg=f"{case} {k}")
+        H.close()
+        D.close()
