@@ -77,6 +77,9 @@ typedef struct {
 	                           where they fit (lossless, bit-identical results): 0 = auto (on when sell_c = 64), 1 = on, 2 = off */
 	int  convert_on;        /* where the SELL delta layout is built from the CSR: 0 = auto (GPU), 1 = GPU (csrc/convert_sell.hip),
 	                           2 = host (OpenMP; kept as the checker — both produce the same bytes)                    */
+	int  symmetric_input;   /* 1 = the CSR arrays hold ONE triangle of a symmetric matrix (KEEP_SYMMETRY builds of the harness:
+	                           csr_to_format(..., symmetric = 1, symmetry_expanded = 0), csr_sym.cpp:118-123); the product is
+	                           y = (T + T^t - diag T) x. Expanded at create(); rows()/nnz() then report the expanded matrix */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */

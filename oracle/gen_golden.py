@@ -11,7 +11,8 @@ file and no golden vectors) the reference's own code path
 is executed through oracle/ref_shim.cpp and its outputs are stored next to the input:
 
     tests/golden/<case>.mtx   input
-    tests/golden/<case>.npz   row_ptr, col_idx, values (fp64), x_rand, and y_<backend>_<prec>_<ones|rand>
+    tests/golden/<case>.npz   row_ptr, col_idx, values (fp64), x_rand, and y_<backend>_<prec>_<ones|rand>;
+                              symmetric files also hold the un-expanded CSR (sym_*) and y_csr_sym_<prec>_<ones|rand>
     tests/golden/manifest.json  per-case header info + the build facts the vectors depend on
 
 Only data (inputs, outputs) is written; no reference source text.
@@ -199,6 +200,12 @@ def main():
     for name, prec in [("csr", "d"), ("csr", "f"), ("csr_kahan", "d"), ("csr_vec", "d"), ("csr_vec", "f"),
                        ("sell_sorted", "d"), ("sell_sorted", "f")]:
         be[(name, prec)] = refdrv.RefBackend(name, prec, "native", threads=THREADS)
+    # symmetric storage (KEEP_SYMMETRY builds, csr_sym.cpp): ONE thread — with more the reference scatters through
+    # compare-and-swap loops in a run-dependent order, so only T = 1 has a reproducible y
+    # (the OpenMP runtime is shared by all the reference libraries of this process: the thread count is switched to 1
+    # around the csr_sym calls only and restored, or sell_sorted's thread-dependent layout would change too)
+    be_sym = {prec: refdrv.RefBackend("csr_sym", prec, "native") for prec in ("d", "f")}
+    be_sym["d"].lib.ref_set_threads(THREADS)
     manifest = {"seed": SEED, "threads": THREADS, "flavour": "native (gcc -O3 -march=native, AVX-512 host)",
                 "vec_len": {"d": 8, "f": 16}, "cases": {}}
     for cname, text in cases.items():
@@ -222,6 +229,18 @@ def main():
             entry[f"format_name_{key}"] = b.format_name
             entry[f"mem_footprint_{key}"] = b.mem_footprint
             entry["csr_mem_footprint_" + prec] = b.csr_mem_footprint
+        if info["symmetric"]:
+            sinfo, sia, sja, sa = be_sym["d"].mtx_to_csr_keep_symmetry(mtx)
+            arrays.update(sym_row_ptr=sia, sym_col_idx=sja, sym_values=sa)
+            entry["sym_nnz"] = sinfo["nnz"]
+            for prec, b in be_sym.items():
+                b.lib.ref_set_threads(1)
+                b.csr_to_format(sia, sja, sa, m, n, symmetric_unexpanded=True)
+                arrays[f"y_csr_sym_{prec}_ones"] = b.spmv(np.ones(n))
+                arrays[f"y_csr_sym_{prec}_rand"] = b.spmv(xr)
+                entry[f"format_name_csr_sym_{prec}"] = b.format_name
+                entry[f"mem_footprint_csr_sym_{prec}"] = b.mem_footprint
+                b.lib.ref_set_threads(THREADS)
         np.savez_compressed(os.path.join(OUT, cname + ".npz"), **arrays)
         manifest["cases"][cname] = entry
         print(f"{cname:22s} m={m} n={n} nnz={info['nnz']} backends={len(entry['backends'])}")

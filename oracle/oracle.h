@@ -114,6 +114,12 @@ double orc_time_csr_spmv_f64(const int32_t * row_ptr, const int32_t * col_idx, c
 		const double * x, double * y, int num_threads, long min_loops, double min_runtime,
 		long * loops_out, double * tmin_out, double * tmax_out);
 
+/* ---- CSR with symmetric storage, one thread (BENCH/spmv_kernels/csr_sym.cpp:191-267); pinned against oracle/_ref */
+void orc_csr_sym_spmv_f64(const int32_t * row_ptr, const int32_t * col_idx, const double * a, long m,
+		const double * x, double * y);
+void orc_csr_sym_spmv_f32(const int32_t * row_ptr, const int32_t * col_idx, const float * a, long m,
+		const float * x, float * y);
+
 /* ---- solver callers of spmv() — PARITY UNPINNED (bench_cg.cpp / bench_bicg.cpp do not compile here; see
  *      solver_oracle.c). history: 3 doubles per loop (error, error_explicit, error_best); info_out[4] =
  *      {eps, eps_counter, err_best, restarts}; return num_loops_out, -1 zero diagonal, -2 not square. */

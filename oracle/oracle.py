@@ -128,6 +128,14 @@ def csr_kahan_spmv(row_ptr, col_idx, a, x):
     return y[:m].copy()
 
 
+def csr_sym_spmv(row_ptr, col_idx, a, x, dtype=np.float64):
+    """y = (L + L^T - diag) x from the stored (lower) triangle as csr_sym.cpp:191-267 computes it with one thread."""
+    row_ptr, col_idx, a, x, y, m = _prep(row_ptr, col_idx, a, x, dtype)
+    f = lib().orc_csr_sym_spmv_f64 if dtype == np.float64 else lib().orc_csr_sym_spmv_f32
+    f(_p(row_ptr), _p(col_idx), _p(a), C.c_long(m), _p(x), _p(y))
+    return y[:m].copy()
+
+
 def csr_vec_spmv(row_ptr, col_idx, a, x, vec_len, dtype=np.float64):
     row_ptr, col_idx, a, x, y, m = _prep(row_ptr, col_idx, a, x, dtype)
     f = lib().orc_csr_vec_spmv_f64 if dtype == np.float64 else lib().orc_csr_vec_spmv_f32

@@ -54,6 +54,25 @@ int ref_mtx_to_csr(const char * filename, long * m, long * n, long * nnz, long *
 	return 0;
 }
 
+// KEEP_SYMMETRY flavour of the same (bench.cpp:131-136,180-192): the file's own entries only (nnz_sym of them, one
+// triangle for symmetric files), converted to CSR by the reference converter.
+int ref_mtx_to_csr_keep_symmetry(const char * filename, long * m, long * n, long * nnz, long * symmetric,
+		int32_t ** row_ptr, int32_t ** col_idx, double ** values)
+{
+	struct Matrix_Market * MTX = mtx_read((char *) filename, 0, 1);
+	long M = MTX->m, N = MTX->n, NNZ = MTX->nnz_sym;
+	*symmetric = MTX->symmetric;
+	mtx_values_convert_to_real(MTX);
+	int32_t * ia = (int32_t *) calloc(M + 1, sizeof(*ia));
+	int32_t * ja = (int32_t *) calloc(NNZ > 0 ? NNZ : 1, sizeof(*ja));
+	double * a = (double *) calloc(NNZ > 0 ? NNZ : 1, sizeof(*a));
+	coo_to_csr(MTX->R, MTX->C, (double *) MTX->V, M, N, NNZ, ia, ja, a, 1, 0);
+	mtx_destroy(&MTX);
+	*m = M; *n = N; *nnz = NNZ;
+	*row_ptr = ia; *col_idx = ja; *values = a;
+	return 0;
+}
+
 void ref_free(void * p) { free(p); }
 
 // COO (0-based) -> CSR through the reference converter (sorted columns, no transpose).
@@ -70,6 +89,14 @@ int ref_csr_to_format(int32_t * row_ptr, int32_t * col_idx, double * values, lon
 {
 	setenv("USE_PROCESSES", "0", 0);   // read without NULL check by the backends' constructors
 	g_MF = csr_to_format(row_ptr, col_idx, values, m, n, nnz, 0, 1);
+	return g_MF == NULL;
+}
+
+// the symmetric-storage backend (csr_sym.cpp) takes symmetric = 1, symmetry_expanded = 0 (csr_sym.cpp:118-123)
+int ref_csr_to_format_symmetric(int32_t * row_ptr, int32_t * col_idx, double * values, long m, long n, long nnz)
+{
+	setenv("USE_PROCESSES", "0", 0);
+	g_MF = csr_to_format(row_ptr, col_idx, values, m, n, nnz, 1, 0);
 	return g_MF == NULL;
 }
 

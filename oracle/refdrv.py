@@ -63,6 +63,22 @@ class RefBackend:
                     nnz_diag=nd.value, nnz_non_diag=nnd.value)
         return info, row_ptr, col_idx, values
 
+    def mtx_to_csr_keep_symmetry(self, path):
+        """KEEP_SYMMETRY loading (bench.cpp:131-136,180-192): the file's own entries only."""
+        L = self.lib
+        m, n, nnz, sym = (C.c_long() for _ in range(4))
+        ia = C.POINTER(C.c_int32)()
+        ja = C.POINTER(C.c_int32)()
+        a = C.POINTER(C.c_double)()
+        L.ref_mtx_to_csr_keep_symmetry(os.fsencode(path), C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym),
+                                       C.byref(ia), C.byref(ja), C.byref(a))
+        row_ptr = np.ctypeslib.as_array(ia, shape=(m.value + 1,)).copy()
+        col_idx = np.ctypeslib.as_array(ja, shape=(max(nnz.value, 1),))[:nnz.value].copy()
+        values = np.ctypeslib.as_array(a, shape=(max(nnz.value, 1),))[:nnz.value].copy()
+        for p in (ia, ja, a):
+            L.ref_free(p)
+        return dict(m=m.value, n=n.value, nnz=nnz.value, symmetric=sym.value), row_ptr, col_idx, values
+
     def coo_to_csr(self, R, Cc, V, m, n):
         R = np.ascontiguousarray(R, np.int32)
         Cc = np.ascontiguousarray(Cc, np.int32)
@@ -75,12 +91,13 @@ class RefBackend:
                                 ia.ctypes, ja.ctypes, a.ctypes)
         return ia, ja[:nnz], a[:nnz]
 
-    def csr_to_format(self, row_ptr, col_idx, values, m, n):
+    def csr_to_format(self, row_ptr, col_idx, values, m, n, symmetric_unexpanded=False):
         ia = np.ascontiguousarray(row_ptr, np.int32)
         ja = np.ascontiguousarray(col_idx, np.int32)
         a = np.ascontiguousarray(values, np.float64)
         self.m, self.n, self.nnz = m, n, len(ja)
-        rc = self.lib.ref_csr_to_format(ia.ctypes, ja.ctypes, a.ctypes, C.c_long(m), C.c_long(n), C.c_long(len(ja)))
+        fn = self.lib.ref_csr_to_format_symmetric if symmetric_unexpanded else self.lib.ref_csr_to_format
+        rc = fn(ia.ctypes, ja.ctypes, a.ctypes, C.c_long(m), C.c_long(n), C.c_long(len(ja)))
         assert rc == 0
         self.format_name = self.lib.ref_format_name().decode()
         self.mem_footprint = self.lib.ref_mem_footprint()

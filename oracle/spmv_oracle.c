@@ -176,6 +176,50 @@ orc_csr_kahan_spmv_f64(const int32_t * row_ptr, const int32_t * col_idx, const d
 	}
 }
 
+/* ================================================================================ CSR, symmetric storage */
+
+/* BENCH/spmv_kernels/csr_sym.cpp:191-267 (subkernel_csr_sym_split + compute_csr) with ONE thread, so i_s = 0, i_e = m
+ * and every column is "inside the thread's range": per stored entry (i, col, a):  sum_upper += a*x[col]  and, off the
+ * diagonal,  y_upper[col] += a*x[i];  after the row  y_upper[i] = sum_upper  (an ASSIGNMENT: contributions that earlier
+ * rows scattered into y_upper[i] would be lost — they do not exist when the stored triangle is the LOWER one, which is
+ * what Matrix-Market symmetric files hold); finally y[i] = 0 + y_upper[i]. The reference build (gcc -O3, default
+ * -ffp-contract=fast) contracts the row sum to an FMA but not the scatter (`prod` is rounded first, csr_sym.cpp:216):
+ * established by trying the four combinations against oracle/_ref/libref_csr_sym_* and pinned bit for bit to it.
+ * With T > 1 the reference scatters through compare-and-swap loops in a run-dependent order: not restated. */
+#define CSR_SYM_BODY(T, FMA)                                                                  \
+	long i, j;                                                                            \
+	for (i = 0; i < m; i++)                                                               \
+		y[i] = 0;                                                                     \
+	for (i = 0; i < m; i++)                                                               \
+	{                                                                                     \
+		T sum_upper = 0;                                                              \
+		for (j = row_ptr[i]; j < row_ptr[i + 1]; j++)                                 \
+		{                                                                             \
+			long col = col_idx[j];                                                \
+			sum_upper = FMA(a[j], x[col], sum_upper);                             \
+			if (i != col)                                                         \
+			{                                                                     \
+				T prod = a[j] * x[i];                                         \
+				y[col] += prod;                                               \
+			}                                                                     \
+		}                                                                             \
+		y[i] = sum_upper;                                                             \
+	}
+
+void
+orc_csr_sym_spmv_f64(const int32_t * row_ptr, const int32_t * col_idx, const double * a, long m,
+		const double * x, double * y)
+{
+	CSR_SYM_BODY(double, fma)
+}
+
+void
+orc_csr_sym_spmv_f32(const int32_t * row_ptr, const int32_t * col_idx, const float * a, long m,
+		const float * x, float * y)
+{
+	CSR_SYM_BODY(float, fmaf)
+}
+
 /* ========================================================================================== CSR vector */
 
 /* BENCH/spmv_kernels/csr_vec.cpp:182-213: VEC_LEN lanes each FMA-accumulate every VEC_LEN-th element of the

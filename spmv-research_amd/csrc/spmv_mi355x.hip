@@ -538,6 +538,116 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 	}
 	HIP_TRY(hipSetDevice(device));
 
+	// ---- symmetric storage in (KEEP_SYMMETRY builds of the harness; csr_sym.cpp:118-123 accepts exactly this): the arrays
+	// hold ONE triangle; the product is y = (T + T^t - diag(T)) x, every stored off-diagonal (i, j, a) also acting as
+	// (j, i, +a) — csr_sym.cpp:204-232, bench_spmv.cpp:135-148. The engine expands it and runs its general kernels:
+	// scattering a*x[i] into y[j] with fp64 atomics runs at 24 G updates/s on MI355X for scattered j (175 G/s perfectly
+	// coalesced; tools/atomic_bench.hip), an order of magnitude short of what halving the matrix stream would need.
+	std::vector<int> e_rp, e_ci;
+	std::vector<double> e_va;
+	if (o.symmetric_input)
+	{
+		if (m != n)
+		{
+			set_error("symmetric_input needs a square matrix (m=%ld n=%ld)", m, n);
+			return 1;
+		}
+		if (row_ptr[0] != 0)
+		{
+			set_error("symmetric_input: row_ptr must start at 0");
+			return 1;
+		}
+		for (long i = 0; i < m; i++)
+			if (row_ptr[i + 1] < row_ptr[i])
+			{
+				set_error("row_ptr is not monotone at row %ld", i);
+				return 1;
+			}
+		std::vector<int> cnt((size_t) m + 1, 0);
+		long bad = -1;
+		#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 4096)
+		for (long i = 0; i < m; i++)
+			for (long j = row_ptr[i]; j < row_ptr[i + 1]; j++)
+			{
+				const int c = col_idx[j];
+				if (c < 0 || c >= n)
+				{
+					#pragma omp atomic write
+					bad = j;
+					continue;
+				}
+				#pragma omp atomic
+				cnt[i + 1]++;
+				if (c != i)
+				{
+					#pragma omp atomic
+					cnt[c + 1]++;
+				}
+			}
+		if (bad >= 0)
+		{
+			set_error("column index %d out of range [0,%ld) at entry %ld", col_idx[bad], n, bad);
+			return 1;
+		}
+		long total = 0;
+		for (long i = 0; i < m; i++)
+			total += cnt[i + 1];
+		if (total >= 0x7fffffffL)
+		{
+			set_error("symmetric_input: the expanded matrix has %ld entries, beyond the int32 index range", total);
+			return 1;
+		}
+		e_rp.assign((size_t) m + 1, 0);
+		for (long i = 0; i < m; i++)
+			e_rp[i + 1] = e_rp[i] + cnt[i + 1];
+		e_ci.resize((size_t) std::max<long>(total, 1));
+		e_va.resize((size_t) std::max<long>(total, 1));
+		std::vector<int> pos(e_rp.begin(), e_rp.end() - 1);
+		#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 4096)
+		for (long i = 0; i < m; i++)
+			for (long j = row_ptr[i]; j < row_ptr[i + 1]; j++)
+			{
+				const int c = col_idx[j];
+				int k;
+				#pragma omp atomic capture
+				k = pos[i]++;
+				e_ci[k] = c;
+				e_va[k] = values[j];
+				if (c != i)
+				{
+					#pragma omp atomic capture
+					k = pos[c]++;
+					e_ci[k] = (int) i;
+					e_va[k] = values[j];
+				}
+			}
+		// rows ascending, columns ascending (what coo_to_csr gives the general path, csr_gen.c:178-213); equal columns are
+		// ordered by value so the result does not depend on the thread interleaving above
+		#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 1024)
+		for (long i = 0; i < m; i++)
+		{
+			const long s0 = e_rp[i], len = e_rp[i + 1] - s0;
+			bool sorted = true;
+			for (long k = 1; k < len && sorted; k++)
+				sorted = e_ci[s0 + k - 1] < e_ci[s0 + k];
+			if (sorted)
+				continue;
+			std::vector<std::pair<int, double>> tmp((size_t) len);
+			for (long k = 0; k < len; k++)
+				tmp[k] = {e_ci[s0 + k], e_va[s0 + k]};
+			std::sort(tmp.begin(), tmp.end());
+			for (long k = 0; k < len; k++)
+			{
+				e_ci[s0 + k] = tmp[k].first;
+				e_va[s0 + k] = tmp[k].second;
+			}
+		}
+		row_ptr = e_rp.data();
+		col_idx = e_ci.data();
+		values = e_va.data();
+		nnz = total;
+	}
+
 	spmv_mi355x_matrix * A = new spmv_mi355x_matrix();
 	A->format = format;
 	A->precision = precision;

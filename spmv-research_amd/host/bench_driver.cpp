@@ -12,6 +12,8 @@
 //                     CSV row (the reference's solver columns) per entry of CG_MAX_NUM_ITERS (space separated,
 //                     bench_cg.cpp:527-553; the reference exits when it is unset, here it defaults to "1000"); the solve
 //                     is the device-resident spmv_mi355x_pcg / spmv_mi355x_pbicgstab of the C ABI.
+//   * KEEP_SYMMETRY=1 (environment) -> the reference's -DKEEP_SYMMETRY build: symmetric files are passed on un-expanded
+//                     (csr_to_format(..., symmetric, 0)) and checked by the symmetric branch of check_accuracy.
 // Environment variables of the reference are honoured when set (GPU_KERNEL, CLEAR_CACHES is N/A on the GPU, PROGG);
 // unlike the reference they may be absent (it dereferences getenv() unchecked: SURVEY §5).
 // Deliberate differences, both reported: GFLOPS uses the TRUE stored nnz (2*nnz/t; the reference multiplies general
@@ -64,10 +66,23 @@ static const char * LABELS =
 // with y_gold > eps exceeds 1e-10 (fp64) / 1e-7 (fp32); then the eight array metrics (lib/array_metrics.c:1477-2149).
 static int
 check_accuracy(char * buf, long buf_n, const INT_T * ia, const INT_T * ja, const double * a, long m,
-		const double * x_ref, const ValueType * y)
+		const double * x_ref, const ValueType * y, bool symmetric_unexpanded)
 {
 	const __float128 epsilon = (sizeof(ValueType) == 8) ? (__float128) 1e-10 : (__float128) 1e-7;
-	std::vector<__float128> gold((size_t) std::max<long>(m, 1));
+	std::vector<__float128> gold((size_t) std::max<long>(m, 1), 0);
+	if (symmetric_unexpanded)
+	{
+		// KEEP_SYMMETRY branch (bench_spmv.cpp:135-148): plain quad accumulation, every off-diagonal entry counted twice
+		for (long i = 0; i < m; i++)
+			for (long j = ia[i]; j < ia[i + 1]; j++)
+			{
+				const long col = ja[j];
+				gold[i] += (__float128) a[j] * (__float128) x_ref[col];
+				if (i != col)
+					gold[col] += (__float128) a[j] * (__float128) x_ref[i];
+			}
+	}
+	else
 	#pragma omp parallel for num_threads(spmv::host_threads())
 	for (long i = 0; i < m; i++)
 	{
@@ -132,6 +147,7 @@ main(int argc, char ** argv)
 	}
 
 	long m = 0, n = 0, nnz = 0, symmetric = 0, nnz_diag = 0, nnz_non_diag = 0;
+	int keep_symmetry = env_int("KEEP_SYMMETRY", 0);
 	std::vector<INT_T> ia, ja;
 	std::vector<double> a_ref;
 	char matrix_name[1000];
@@ -153,6 +169,7 @@ main(int argc, char ** argv)
 			return 1;
 		}
 		printf("time generate twin: %lf\n", now() - t);
+		keep_symmetry = 0;                                               // the twins are general matrices
 		m = csr.m; n = csr.n; nnz = csr.nnz;
 		ia.assign(csr.row_ptr, csr.row_ptr + m + 1);
 		ja.assign(csr.col_idx, csr.col_idx + nnz);
@@ -175,6 +192,12 @@ main(int argc, char ** argv)
 		}
 		printf("time read: %lf\n", now() - t);
 		m = coo.m; n = coo.n; nnz = coo.nnz; symmetric = coo.symmetric;
+		// KEEP_SYMMETRY=1 in the environment = the reference's -DKEEP_SYMMETRY build (bench.cpp:131-136,186-192): only the
+		// file's own entries (the first nnz_sym of the expanded list) go on, flagged symmetric and NOT expanded
+		if (keep_symmetry && symmetric)
+			nnz = coo.nnz_sym;
+		else
+			keep_symmetry = 0;
 		nnz_diag = coo.nnz_diag; nnz_non_diag = coo.nnz_non_diag;
 		t = now();
 		ia.assign((size_t) m + 1, 0);
@@ -192,7 +215,7 @@ main(int argc, char ** argv)
 	const long nnz_expanded_symmetry = 2 * nnz_non_diag + nnz_diag;      // bench.cpp:212 (quirk Q4)
 
 	t = now();
-	struct Matrix_Format * MF = csr_to_format(ia.data(), ja.data(), a_ref.data(), m, n, nnz, symmetric, 1);
+	struct Matrix_Format * MF = csr_to_format(ia.data(), ja.data(), a_ref.data(), m, n, nnz, symmetric, keep_symmetry ? 0 : 1);
 	printf("time convert to format: %lf\n", now() - t);
 
 	// "Reallocate CSR arrays to ensure the format does not rely on them" (bench.cpp:605-629)
@@ -316,7 +339,7 @@ main(int argc, char ** argv)
 	i += snprintf(buf + i, sizeof(buf) - i, ",%lf,%lf,%lf", MF->csr_mem_footprint / (1024 * 1024), 0.0, 0.0);
 	i += snprintf(buf + i, sizeof(buf) - i, ",%s,%lu,%lu,%lu", MF->format_name, MF->m, MF->n, MF->nnz);
 	i += snprintf(buf + i, sizeof(buf) - i, ",%lf,%lf,%ld", MF->mem_footprint / (1024 * 1024), MF->mem_footprint / MF->csr_mem_footprint, num_loops);
-	i += check_accuracy(buf + i, sizeof(buf) - i, ia.data(), ja.data(), a_ref.data(), m, x_ref.data(), y);
+	i += check_accuracy(buf + i, sizeof(buf) - i, ia.data(), ja.data(), a_ref.data(), m, x_ref.data(), y, keep_symmetry != 0);
 	fprintf(stderr, "%s\n", buf);
 	free(x);
 	free(y);

@@ -54,7 +54,7 @@ struct MI355XFormat : Matrix_Format
 {
 	spmv_mi355x_matrix * handle;
 
-	MI355XFormat(INT_T * row_ptr, INT_T * col_ind, ValueTypeReference * values, long m, long n, long nnz)
+	MI355XFormat(INT_T * row_ptr, INT_T * col_ind, ValueTypeReference * values, long m, long n, long nnz, int symmetric_input)
 		: Matrix_Format(m, n, nnz), handle(NULL)
 	{
 		spmv_mi355x_opts o;
@@ -65,6 +65,7 @@ struct MI355XFormat : Matrix_Format
 		o.sell_c = env_int("SPMV_MI355X_SELL_C", 0);
 		o.sell_sigma = env_int("SPMV_MI355X_SELL_SIGMA", 0);
 		o.merge_items = env_int("SPMV_MI355X_MERGE_ITEMS", 0);
+		o.symmetric_input = symmetric_input;
 		const int precision = (sizeof(ValueType) == 8) ? SPMV_MI355X_F64 : SPMV_MI355X_F32;
 		// deep copy happens inside create(): the driver frees its CSR right after this call (bench.cpp:605-629)
 		if (spmv_mi355x_create(&handle, chosen_format(), precision, m, n, nnz, row_ptr, col_ind, values, &o))
@@ -88,9 +89,10 @@ struct MI355XFormat : Matrix_Format
 struct Matrix_Format *
 csr_to_format(INT_T * row_ptr, INT_T * col_ind, ValueTypeReference * values, long m, long n, long nnz, long symmetric, long symmetry_expanded)
 {
-	if (symmetric && !symmetry_expanded)
-		mi355x_error("symmetric matrices have to be expanded to be supported by this format");   // csr.cpp:224-225
-	MI355XFormat * mf = new MI355XFormat(row_ptr, col_ind, values, m, n, nnz);
+	// Both conventions of the harness are accepted: expanded input (the default build, csr.cpp:221-226) and, in KEEP_SYMMETRY
+	// builds, one stored triangle (symmetric = 1, symmetry_expanded = 0: what csr_sym.cpp:118-123 takes). Matrix_Format's
+	// m/n/nnz/csr_mem_footprint stay those of the arrays the harness passed, as in the reference.
+	MI355XFormat * mf = new MI355XFormat(row_ptr, col_ind, values, m, n, nnz, (symmetric && !symmetry_expanded) ? 1 : 0);
 	if (env_int("SPMV_MI355X_ALWAYS_COPY", 0))
 		spmv_mi355x_set_always_copy(mf->handle, 1);
 	return mf;

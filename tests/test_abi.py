@@ -28,11 +28,24 @@ def test_every_declared_symbol_is_exported(header, module):
     assert sorted(mod.SYMBOLS) == names, "python binding symbol list out of date with the header"
 
 
-def test_opts_struct_layout_matches_header():
+def test_opts_struct_layout_matches_header(tmp_path):
+    """sizeof and every field offset of the ctypes mirrors against what a C compiler makes of include/spmv_mi355x.h"""
+    import subprocess
     import spmv_mi355x as E
-    # 10 ints, 4 longs, 2 ints (include/spmv_mi355x.h: spmv_mi355x_opts)
-    assert ctypes.sizeof(E.Opts) == 10 * 4 + 4 * 8 + 2 * 4
-    assert E.Opts.row_begin.offset == 40 and E.Opts.col_filter_mode.offset == 72
+    lines = []
+    for cname, cls in (("spmv_mi355x_opts", E.Opts), ("spmv_mi355x_solver_info", E.SolverInfo)):
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "spmv_mi355x.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in (("spmv_mi355x_opts", E.Opts), ("spmv_mi355x_solver_info", E.SolverInfo)):
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
 
 
 @pytest.mark.skipif(has_gpu(), reason="CPU tier only: checks the no-device failure mode")

@@ -325,3 +325,67 @@ def test_device_conversion_on_golden_cases(eng):
             np.testing.assert_array_equal(ld[k], lh[k], err_msg=f"{case} {k}")
         H.close()
         D.close()
+
+
+# ---- symmetric storage in (row f4: KEEP_SYMMETRY builds, csr_sym.cpp) -------------------------------------------------------
+
+SYM_CASES = [c for c in CASES if MANIFEST["cases"][c].get("sym_nnz") is not None]
+
+
+@pytest.mark.parametrize("case", SYM_CASES)
+def test_symmetric_input_matches_reference_csr_sym(eng, oracle, case):
+    """One stored triangle in, y = (T + T^t - diag T) x out. Against the reference csr_sym build's y (fixtures, T = 1) to
+    the reordering tolerance, and BIT-identical to the same engine fed the expansion — the expansion is the whole change."""
+    info, z = load_case(case)
+    m, n = info["m"], info["n"]
+    rp, ci, a = z["sym_row_ptr"], z["sym_col_idx"], z["sym_values"]
+    # the expansion csr_sym implies: every off-diagonal (i, j, a) also as (j, i, +a) — for skew / Hermitian FILES this is NOT
+    # the general-path matrix (which negates / conjugates the mirror image); the symmetric-storage kernel of the reference
+    # ignores that too (csr_sym.cpp:204-232, bench_spmv.cpp:135-148)
+    import scipy.sparse as sp
+    rows = np.repeat(np.arange(m), np.diff(rp))
+    off = rows != ci
+    E = sp.coo_matrix((np.concatenate([a, a[off]]), (np.concatenate([rows, ci[off]]), np.concatenate([ci, rows[off]]))), shape=(m, n))
+    E = E.tocsr()           # duplicates are summed by scipy: none of the symmetric fixtures has any
+    assert E.nnz == 2 * len(ci) - int((~off).sum())
+    E.sort_indices()
+    for dtype, prec in ((np.float64, "d"), (np.float32, "f")):
+        for xname, x in (("ones", np.ones(n)), ("rand", z["x_rand"])):
+            y_ref = z[f"y_csr_sym_{prec}_{xname}"]
+            absrow = abs(E) @ np.abs(x)
+            for fmt, opts, _ in VARIANTS[::4]:
+                S = eng.Matrix(rp, ci, a, m, n, fmt, dtype, symmetric_input=1, **opts)
+                G = eng.Matrix(E.indptr, E.indices, E.data, m, n, fmt, dtype, **opts)
+                assert S.nnz == E.nnz and S.m == m
+                y = S.spmv(x)
+                check(y, y_ref, absrow, dtype, False, f"{case}/{fmt}{opts}/sym/{prec}/{xname}")
+                np.testing.assert_array_equal(y, G.spmv(x))
+                S.close()
+                G.close()
+
+
+def test_symmetric_input_rejects_bad_input(eng):
+    rp = np.array([0, 1, 3], np.int32)
+    ci = np.array([0, 0, 1], np.int32)
+    with pytest.raises(eng.SpmvError, match="square"):
+        eng.Matrix(rp, ci, np.ones(3), 2, 3, "csr_vector", symmetric_input=1)
+    with pytest.raises(eng.SpmvError, match="out of range"):
+        eng.Matrix(rp, np.array([0, 0, 7], np.int32), np.ones(3), 2, 2, "csr_vector", symmetric_input=1)
+
+
+def test_driver_keep_symmetry_mode(eng):
+    """KEEP_SYMMETRY=1 ./spmv_mi355x_bench file.mtx = the reference's -DKEEP_SYMMETRY build: un-expanded arrays in, the
+    symmetric branch of check_accuracy (bench_spmv.cpp:135-148) as the judge."""
+    import os
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "spmv-research_amd", "bin", "spmv_mi355x_bench")
+    for case in ("symmetric_real", "banded_symmetric"):
+        info = MANIFEST["cases"][case]
+        env = dict(os.environ, KEEP_SYMMETRY="1", GPU_KERNEL="0", SPMV_MI355X_FORMAT="sell_c_sigma")
+        r = subprocess.run([exe, os.path.join(GOLDEN, case + ".mtx")], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        assert "Test failed" not in r.stdout
+        row = r.stderr.strip().splitlines()[-1].split(",")
+        assert int(row[4]) == info["sym_nnz"] and int(row[5]) == 1          # csr_nnz = stored triangle, symmetry flag
+        assert float(row[22]) < 1e-12                                       # spmv_max_ae against the symmetric quad gold

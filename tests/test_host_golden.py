@@ -280,3 +280,21 @@ def test_reader_reports_corrupt_compressed_input(tmp_path):
     (tmp_path / "e.tar").write_bytes(b"\0" * 1024)
     with pytest.raises(Exception, match="no regular file"):
         H.mtx_read(str(tmp_path / "e.tar"))
+
+
+def test_reader_keeps_the_file_entries_first_for_keep_symmetry_callers():
+    """KEEP_SYMMETRY builds (bench.cpp:131-136,186-192) pass only the file's own entries on: they are the first nnz_sym
+    entries of the expanded COO. coo_to_csr of that prefix must equal the reference's un-expanded CSR."""
+    import spmv_host as H
+    n_checked = 0
+    for case in CASES:
+        info, z = load_case(case)
+        if "sym_row_ptr" not in z:
+            continue
+        coo, R, Cc, V = H.mtx_read(os.path.join(GOLDEN, case + ".mtx"))
+        k = coo["nnz_sym"]
+        assert k == info["sym_nnz"]
+        rp, ci, a = H.coo_to_csr(R[:k], Cc[:k], V[:k], coo["m"], coo["n"])
+        assert np.array_equal(rp, z["sym_row_ptr"]) and np.array_equal(ci, z["sym_col_idx"]) and np.array_equal(a, z["sym_values"])
+        n_checked += 1
+    assert n_checked >= 5

@@ -119,3 +119,20 @@ def test_gold_and_metrics(oracle, case):
     # fp32 kernel fails the 1e-7 threshold by construction (Q10) but stays within fp32 rounding of the row mass
     _, metf = oracle.check_accuracy(rp, ci, a, x, g["y_csr_f_rand"].astype(np.float64), False)
     assert metf["max_ae"] <= 64 * 6e-8 * max(absrow.max(), 1e-30)
+
+
+# ---- symmetric storage (row f4): csr_sym.cpp with one thread, pinned bit for bit by the reference build ------------------
+
+SYM_CASES = [c for c in CASES if MANIFEST["cases"][c].get("sym_nnz") is not None]
+
+
+@pytest.mark.parametrize("case", SYM_CASES)
+def test_csr_sym_oracle_reproduces_the_reference(oracle, case):
+    info, z = load_case(case)
+    rp, ci, a = z["sym_row_ptr"], z["sym_col_idx"], z["sym_values"]
+    assert len(ci) == info["sym_nnz"] and info["format_name_csr_sym_d"] == "CSR_SYM_CPU"
+    assert np.all(ci <= np.repeat(np.arange(info["m"]), np.diff(rp))), "Matrix-Market symmetric files hold the lower triangle"
+    for prec, dt in (("d", np.float64), ("f", np.float32)):
+        for xname, x in (("ones", np.ones(info["n"])), ("rand", z["x_rand"])):
+            y = oracle.csr_sym_spmv(rp, ci, a, x, dt)
+            assert np.array_equal(y, z[f"y_csr_sym_{prec}_{xname}"]), (case, prec, xname)
