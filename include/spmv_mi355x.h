@@ -67,7 +67,9 @@ typedef struct {
 	int  stream_mode;       /* CSR_STREAM: 0 = auto (3); 1 = products staged in LDS (row-major x gather); 2 = (value,column)
 	                           pairs staged in LDS through registers, lanes walk rows (coalesced x gathers); 3 = the same with
 	                           the global->LDS copy done by LDS-DMA (global_load_lds). With 64 rows per wave 2 and 3 are
-	                           bit-exact                                                                              */
+	                           bit-exact; 4 = nnz-balanced row blocks whose window of x is copied into LDS (up to 128 KiB) and
+	                           gathered from there, lanes_per_row lanes per row (8..64), merge_items = blocks per CU (0 auto);
+	                           for matrices whose row blocks touch a narrow column range (FEM / banded)                   */
 	long row_begin;         /* row block [row_begin,row_end) of the GLOBAL CSR to keep on this device (row-partitioned */
 	long row_end;           /*   multi-GPU, §8e); 0,0 = all rows. x stays full length n; y has row_end-row_begin rows. */
 	long col_begin;         /* optional column filter [col_begin,col_end) used for the local/remote split that lets    */
@@ -80,6 +82,8 @@ typedef struct {
 	int  symmetric_input;   /* 1 = the CSR arrays hold ONE triangle of a symmetric matrix (KEEP_SYMMETRY builds of the harness:
 	                           csr_to_format(..., symmetric = 1, symmetry_expanded = 0), csr_sym.cpp:118-123); the product is
 	                           y = (T + T^t - diag T) x. Expanded at create(); rows()/nnz() then report the expanded matrix */
+	int  rows_per_group;    /* CSR_VECTOR: consecutive rows a lane group keeps in flight together (1, 2 or 4; 2 and 4 need
+	                           lanes_per_row >= 8); 0 = auto                                                        */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */

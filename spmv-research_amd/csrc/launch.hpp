@@ -16,7 +16,7 @@ struct LaunchCfg {
 
 // tile geometry of each kernel family (units per workgroup), needed to build the XCD map
 inline long csr_scalar_rows_per_tile() { return 256; }
-inline long csr_vector_rows_per_tile(int lanes_per_row) { return 256 / lanes_per_row; }
+inline long csr_vector_rows_per_tile(int lanes_per_row, int rows_per_group = 1) { return 256L / lanes_per_row * rows_per_group; }
 inline long csr_stream_rows_per_tile(int rows_per_wave) { return 4L * rows_per_wave; }
 inline long sell_slices_per_tile() { return 4; }
 inline long coo_waves_per_tile() { return 4; }
@@ -24,7 +24,7 @@ inline long coo_waves_per_tile() { return 4; }
 // ---- CSR (kernels_csr.hip)
 int launch_csr_scalar(bool f32, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
 		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
-int launch_csr_vector(bool f32, int lanes_per_row, const int * row_ptr, const int * col, const void * val,
+int launch_csr_vector(bool f32, int lanes_per_row, int rows_per_group, const int * row_ptr, const int * col, const void * val,
 		const void * x, void * y, int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
 // ---- CSR-Stream: one wavefront per block of R consecutive rows (kernels_csr_stream.hip)
@@ -41,6 +41,12 @@ long csr_stream_d_rows_per_tile(int rows_per_wave);                    // rows p
 int launch_csr_stream_d(bool f32, int rows_per_wave, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
 		int m, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 constexpr int STREAM_SLACK = 512;                                      // entries the LDS-DMA copy may read past a row block
+
+// CSR with the block's x window in LDS (kernels_csr_window.hip)
+int csr_window_lds_budget();                                           // bytes of LDS a block's window may take
+int launch_csr_window(bool f32, int lanes_per_row, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+		const int * blk_row, const int * blk_lo, const int * blk_w, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream,
+		long * grid_out);
 
 // ---- merge-path CSR (kernels_merge.hip)
 int merge_tile_items(bool f32, int items_per_thread);                 // merge items (rows + nnz) per workgroup

@@ -45,6 +45,11 @@ struct spmv_mi355x_matrix {
 	int * d_col = nullptr;
 	void * d_val = nullptr;
 	int lanes_per_row = 0;
+	int rows_per_group = 1;                // CSR_VECTOR: rows a lane group keeps in flight (1, 2, 4)
+	int * d_win_row = nullptr;             // CSR_STREAM mode 4: row block boundaries, window start, window length (0 = no LDS window)
+	int * d_win_lo = nullptr;
+	int * d_win_w = nullptr;
+	int win_blocks = 0, win_lds_bytes = 0;
 	int stream_mode = 0;                   // CSR_STREAM: 1 = products in LDS (row-major gather), 2 = (val,col) in LDS, lane-per-row walk
 	// merge
 	int merge_ipt = 0, merge_tile = 0, merge_num_tiles = 0;
@@ -106,7 +111,8 @@ static void
 free_all(spmv_mi355x_matrix * A)
 {
 	void * ptrs[] = {A->d_row_ptr, A->d_col, A->d_val, A->d_coords, A->d_carry_row, A->d_carry_val, A->d_slice_ptr,
-	                 A->d_row_of_sorted, A->d_rowind, A->d_x, A->d_y, A->d_sell_desc, A->d_sell_idx};
+	                 A->d_row_of_sorted, A->d_rowind, A->d_x, A->d_y, A->d_sell_desc, A->d_sell_idx, A->d_win_row, A->d_win_lo,
+	                 A->d_win_w};
 	for (void * p : ptrs)
 		if (p)
 			(void) hipFree(p);
@@ -783,6 +789,77 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 				int R = o.lanes_per_row;
 				const double mean = lm > 0 ? (double) lnnz / lm : 0;
 				int mode = o.stream_mode;
+				// x window in LDS (kernels_csr_window.hip): nnz-balanced row blocks, a multiple of the 256 CUs. Forced by
+				// stream_mode 4; in auto mode adopted when (nearly) every block's window fits the LDS budget and rows are long
+				// enough to amortise the per-row butterfly (measured: pwtk twin fp32 22.1 -> 18.6 us; short-row / scattered
+				// matrices keep the other modes; fp64 windows of ~100 KiB and matrices under 8 M non-zeros did not gain).
+				auto try_window = [&](bool force) -> int {
+					int G = R ? R : std::max(8, pick_lanes_per_row(mean));
+					if (G != 8 && G != 16 && G != 32 && G != 64)
+					{
+						if (!force)
+							return 0;
+						set_error("csr_stream mode 4: lanes_per_row must be 8, 16, 32 or 64 (got %d)", G);
+						return -1;
+					}
+					const int NG = 1024 / G;
+					long nb = 256L * (o.merge_items > 0 ? o.merge_items : std::max(1L, std::min(8L, lnnz / (256L * 24576L))));
+					nb = std::max(1L, std::min(nb, (lm + 2 * NG - 1) / (2 * NG)));
+					std::vector<int> b_row((size_t) nb + 1), b_lo((size_t) nb, 0), b_w((size_t) nb, 0);
+					std::vector<long> b_nnz((size_t) nb + 1);
+					for (long b = 0; b <= nb; b++)
+					{
+						const long target = (long) ((double) lnnz * b / nb);
+						long r = std::lower_bound(rp, rp + lm + 1, (int) std::min<long>(target, 0x7fffffffL)) - rp;
+						b_row[b] = (int) (b == 0 ? 0 : b == nb ? lm : std::min<long>(std::max<long>(r, b_row[b - 1]), lm));
+						b_nnz[b] = rp[b_row[b]];
+					}
+					const long budget = csr_window_lds_budget() / (long) A->vbytes;
+					long with_window = 0;
+					int max_w = 0;
+					#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4) reduction(+ : with_window) reduction(max : max_w)
+					for (long b = 0; b < nb; b++)
+					{
+						int lo = 0x7fffffff, hi = -1;
+						for (long j = rp[b_row[b]]; j < rp[b_row[b + 1]]; j++)
+						{
+							lo = std::min(lo, ci[j]);
+							hi = std::max(hi, ci[j]);
+						}
+						if (hi >= 0 && (long) hi - lo + 1 <= budget)
+						{
+							b_lo[b] = lo;
+							b_w[b] = hi - lo + 1;
+							with_window++;
+							max_w = std::max(max_w, b_w[b]);
+						}
+					}
+					if (!force && (with_window * 100 < nb * 95 || mean < 16 || !A->f32 || lnnz < (8L << 20)))
+						return 0;
+					A->stream_mode = 4;
+					A->lanes_per_row = G;
+					A->win_blocks = (int) nb;
+					A->win_lds_bytes = (int) (((long) max_w * A->vbytes + 15) / 16 * 16);
+					if (upload_ints(b_row.data(), (size_t) nb + 1, &A->d_win_row) || upload_ints(b_lo.data(), (size_t) nb, &A->d_win_lo) ||
+					    upload_ints(b_w.data(), (size_t) nb, &A->d_win_w))
+						return -1;
+					A->cfg.map = xcd_map_balanced(b_nnz.data(), nb, 1, resolve_remap(A->remap, nb));
+					A->mem_footprint += (3.0 * nb + 1) * 4;
+					snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_WINDOW_g%d_b%ld_w%ld_%s", G, nb, with_window * 100 / nb, pf);
+					snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_window_kernel");
+					return 1;
+				};
+				if (mode == 4 || (mode == 0 && R == 0))
+				{
+					const int took = try_window(mode == 4);
+					if (took < 0)
+					{
+						rc = 1;
+						break;
+					}
+					if (took > 0)
+						break;
+				}
 				if (mode < 1 || mode > 3)
 				{
 					// The lane-per-row walk (modes 2/3) pays when neighbouring rows touch neighbouring columns (stencil /
@@ -857,9 +934,30 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 					break;
 				}
 				A->lanes_per_row = G;
-				A->cfg.map = xcd_map_balanced(rp, lm, csr_vector_rows_per_tile(G), resolve_remap(A->remap, lm / csr_vector_rows_per_tile(G)));
-				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_VECTOR_g%d_%s", G, pf);
-				snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_vector_kernel");
+				int RPG = o.rows_per_group;
+				if (RPG == 0)
+				{
+					// two rows of a lane group in flight: measured +10 % on the nlpkkt240 twin (2.90 -> 2.63 ms), +8 % on
+					// scircuit as 16 lanes x 2 rows instead of 8 lanes x 1, neutral on cant / pwtk fp64; four rows cost occupancy
+					if (G == 8 && o.lanes_per_row == 0)
+						G = 16;
+					RPG = (G == 16 || G == 32) ? 2 : 1;
+					A->lanes_per_row = G;
+				}
+				if ((RPG != 1 && RPG != 2 && RPG != 4) || (RPG > 1 && G < 8))
+				{
+					set_error("rows_per_group must be 1, 2 or 4 (2 and 4 need lanes_per_row >= 8), got %d with %d lanes", RPG, G);
+					rc = 1;
+					break;
+				}
+				A->rows_per_group = RPG;
+				const long rpt = csr_vector_rows_per_tile(G, RPG);
+				A->cfg.map = xcd_map_balanced(rp, lm, rpt, resolve_remap(A->remap, lm / rpt));
+				if (RPG > 1)
+					snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_VECTOR_g%d_r%d_%s", G, RPG, pf);
+				else
+					snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_VECTOR_g%d_%s", G, pf);
+				snprintf(A->kernel_name, sizeof(A->kernel_name), RPG > 1 ? "csr_vector_multi_kernel" : "csr_vector_kernel");
 			}
 			else
 			{
@@ -1010,10 +1108,13 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 			rc = launch_csr_scalar(A->f32, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_CSR_VECTOR:
-			rc = launch_csr_vector(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
+			rc = launch_csr_vector(A->f32, A->lanes_per_row, A->rows_per_group, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_CSR_STREAM:
-			rc = (A->stream_mode == 3)
+			rc = (A->stream_mode == 4)
+			     ? launch_csr_window(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, A->d_win_row, A->d_win_lo, A->d_win_w,
+					A->win_lds_bytes, cfg, st, &grid)
+			     : (A->stream_mode == 3)
 			     ? launch_csr_stream_d(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid)
 			     : (A->stream_mode == 2)
 			     ? launch_csr_stream_t(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid)

@@ -26,6 +26,10 @@ VARIANTS = [
     ("csr_vector", {"lanes_per_row": 32}, False),
     ("csr_vector", {"lanes_per_row": 64}, False),      # the literal "one wavefront per row" of config 2
     ("csr_vector", {}, False),                          # auto
+    ("csr_vector", {"lanes_per_row": 16, "rows_per_group": 4}, False),   # several rows of a lane group in flight
+    ("csr_vector", {"lanes_per_row": 8, "rows_per_group": 2}, False),
+    ("csr_vector", {"lanes_per_row": 8, "rows_per_group": 4}, False),
+    ("csr_vector", {"lanes_per_row": 64, "rows_per_group": 2}, False),
     ("csr_stream", {}, False),
     ("csr_stream", {"lanes_per_row": 64}, False),                         # LDS-DMA, lane per row (exact only while the block fits the strip)
     ("csr_stream", {"lanes_per_row": 32}, False),
@@ -38,6 +42,10 @@ VARIANTS = [
     ("csr_stream", {"stream_mode": 1, "lanes_per_row": 4}, False),        # products in LDS
     ("csr_stream", {"stream_mode": 1, "lanes_per_row": 16}, False),
     ("csr_stream", {"stream_mode": 1, "lanes_per_row": 64}, False),
+    ("csr_stream", {"stream_mode": 4}, False),                            # x window of the row block in LDS
+    ("csr_stream", {"stream_mode": 4, "lanes_per_row": 8, "merge_items": 1}, False),
+    ("csr_stream", {"stream_mode": 4, "lanes_per_row": 32, "merge_items": 3}, False),
+    ("csr_stream", {"stream_mode": 4, "lanes_per_row": 64}, False),
     ("csr_merge", {}, False),
     ("csr_merge", {"merge_items": 5}, False),
     ("csr_merge", {"merge_items": 13}, False),

@@ -100,7 +100,8 @@ static double timeit(F f, int iters)
 
 int main(int argc, char ** argv)
 {
-	const long rows = 28L * 1000 * 1000 / 128 * 128;
+	const long rows = (argc > 1 ? atol(argv[1]) : 28L * 1000 * 1000) / 128 * 128;      // argv[1]: rows (28 per row, 12 B each)
+	const int reps = argc > 2 ? atoi(argv[2]) : 10;
 	const int W = 28;                       // elements per row
 	const long nnz = rows * W;
 	printf("rows %ld nnz %ld  matrix bytes %.2f GB\n", rows, nnz, nnz * 12 / 1e9);
@@ -125,7 +126,7 @@ int main(int argc, char ** argv)
 	const double bytes = nnz * 12.0 + rows * 16.0;
 	const long slices = rows / 64;
 	const unsigned grid = (unsigned) ((slices + 3) / 4);
-	#define RUN(name, ...) { double ms = timeit([&] { hipLaunchKernelGGL(__VA_ARGS__); }, 10); printf("%-40s %8.3f ms %8.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); }
+	#define RUN(name, ...) { timeit([&] { hipLaunchKernelGGL(__VA_ARGS__); }, reps); double ms = timeit([&] { hipLaunchKernelGGL(__VA_ARGS__); }, reps); printf("%-40s %8.3f ms %8.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); }
 	RUN("stream u4",          (k_sell_like<4, false, 0, false>), dim3(grid), dim3(256), 0, 0, dv, dc, dx, dy, slices, W);
 	RUN("stream u4 nt",       (k_sell_like<4, true, 0, false>), dim3(grid), dim3(256), 0, 0, dv, dc, dx, dy, slices, W);
 	RUN("stream u7 nt",       (k_sell_like<7, true, 0, false>), dim3(grid), dim3(256), 0, 0, dv, dc, dx, dy, slices, W);

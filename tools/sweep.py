@@ -17,12 +17,18 @@ def variants(dts):
     v = [("csr_scalar", {}), ("csr_vector", {}), ("csr_stream", {}), ("csr_merge", {}), ("sell_c_sigma", {}), ("coo", {})]   # auto
     for g in (2, 4, 8, 16, 32, 64):
         v.append(("csr_vector", {"lanes_per_row": g}))
+    for g in (8, 16, 32):
+        for rpg in (2, 4):
+            v.append(("csr_vector", {"lanes_per_row": g, "rows_per_group": rpg}))
     for r in (4, 8, 16, 32, 64):
         v.append(("csr_stream", {"lanes_per_row": r}))
     for r in (32,):
         v.append(("csr_stream", {"lanes_per_row": r, "stream_mode": 2}))
     for r in (8, 16):
         v.append(("csr_stream", {"lanes_per_row": r, "stream_mode": 1}))
+    for g in (8, 16, 32):
+        for k in (1, 2, 4):
+            v.append(("csr_stream", {"stream_mode": 4, "lanes_per_row": g, "merge_items": k}))
     for i in (5, 7, 9, 11, 13):
         v.append(("csr_merge", {"merge_items": i}))
     for c in (16, 32, 64):
