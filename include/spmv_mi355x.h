@@ -127,6 +127,10 @@ int  spmv_mi355x_time_device(spmv_mi355x_matrix * A, const void * x_dev, void * 
 /* Name and launch shape of the dominant kernel (for matching rocprofv3 kernel-trace rows). */
 int  spmv_mi355x_kernel_info(const spmv_mi355x_matrix * A, char * name_out, long name_n, long * grid_out, int * block_out);
 
+/* dst_dev[0..bytes) = src_dev[0..bytes), enqueued on hip_stream: lets a caller without HIP headers (the ctypes / cgo side of
+ * the distributed solver callbacks) move a vector slice into its exchange buffer. */
+int  spmv_mi355x_copy_device_async(void * dst_dev, const void * src_dev, long bytes, void * hip_stream);
+
 /* Device buffers owned by the handle (allocated lazily by the host-buffer entry points). */
 void * spmv_mi355x_x_device(spmv_mi355x_matrix * A);
 void * spmv_mi355x_y_device(spmv_mi355x_matrix * A);
@@ -156,6 +160,33 @@ int  spmv_mi355x_pcg(spmv_mi355x_matrix * A, const int32_t * row_ptr, const int3
 		const void * b_host, void * x_res_out_host, long max_iterations, double * history_out, spmv_mi355x_solver_info * info);
 int  spmv_mi355x_pbicgstab(spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t * col_idx, const double * values_fp64,
 		const void * b_host, void * x_res_out_host, long max_iterations, double * history_out, spmv_mi355x_solver_info * info);
+
+/* Row-partitioned (multi-GPU) form of the same two solvers: one process per GPU owns the row block [row_offset,
+ * row_offset + m_local) of A, b and x. The solver keeps every vector device-resident and local; the two things that cross
+ * ranks are handed to the caller, who has the communicator (torch.distributed / RCCL in bench-level code):
+ *   spmv(ctx, in_dev, out_dev)           out_local = (A * in)_local where `in` is this rank's slice of the global vector
+ *                                        (exchange of the slices + the local SpMV launches, e.g. §8e's allgather(x) scheme)
+ *   allreduce_sum(ctx, reduce_buf_dev, count)   in-place sum over the ranks of `count` doubles in reduce_buf_dev
+ * Both are called on the host between kernel launches and must ENQUEUE their work on the NULL stream (or order against
+ * it); nothing waits for the host. Per iteration: CG 1 spmv + 2 all-reduces (1 and 2 doubles), BiCGSTAB 2 spmv + 3
+ * all-reduces. All ranks compute identical scalars, take the `err < eps` break at the same iteration and return the same
+ * history/info; the values equal the single-GPU solver's up to the summation order of the dots.
+ * row_ptr_local has m_local+1 entries starting at 0; col_idx_global holds GLOBAL column indices (the Jacobi diagonal of
+ * local row i is the first entry with column row_offset + i); b / x are the local slices (host, handle precision). */
+typedef struct {
+	unsigned struct_size;      /* sizeof(spmv_mi355x_dist_ops) */
+	long   row_offset;
+	int  (*spmv)(void * ctx, const void * in_dev, void * out_dev);
+	int  (*allreduce_sum)(void * ctx, double * reduce_buf_dev, int count);
+	double * reduce_buf_dev;   /* device scratch of >= 4 doubles owned by the caller (so it can be a tensor of its framework) */
+	void * ctx;
+} spmv_mi355x_dist_ops;
+int  spmv_mi355x_pcg_dist(const spmv_mi355x_dist_ops * ops, int precision, long m_local, const int32_t * row_ptr_local,
+		const int32_t * col_idx_global, const double * values_fp64, const void * b_local_host, void * x_local_out_host,
+		long max_iterations, double * history_out, spmv_mi355x_solver_info * info);
+int  spmv_mi355x_pbicgstab_dist(const spmv_mi355x_dist_ops * ops, int precision, long m_local, const int32_t * row_ptr_local,
+		const int32_t * col_idx_global, const double * values_fp64, const void * b_local_host, void * x_local_out_host,
+		long max_iterations, double * history_out, spmv_mi355x_solver_info * info);
 
 /* ---- format introspection for parity tests (host copies of the converted arrays) -------------------------- */
 /* SELL-C-sigma layout: any out pointer may be NULL. Arrays are malloc'ed copies; free with spmv_mi355x_free().

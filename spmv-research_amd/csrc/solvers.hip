@@ -90,14 +90,36 @@ store_partial(double * __restrict__ part, int slot, double v)
 		part[(long) slot * MAX_PART + blockIdx.x] = v;
 }
 
-// (iterations the device has finished, break flag) for the host, in host-mapped pinned memory
+// (iterations the device has finished, loop count at the break or -1) for the host, in host-mapped pinned memory
 __device__ __forceinline__ void
-post_progress(volatile long * host_progress, long finished, int done)
+post_progress(volatile long * host_progress, long finished, long broke_at)
 {
-	host_progress[1] = done;
+	host_progress[1] = broke_at;
 	__threadfence_system();
 	host_progress[0] = finished;
 	__threadfence_system();
+}
+
+// Distributed solves: the per-block partials of up to 3 slots are summed into red[], all-reduced over the ranks by the
+// caller's collective, and written back as the single partial of their slot (consumers then run with nb = 1).
+struct SlotList {
+	int n;
+	int s[3];
+};
+
+__global__ __launch_bounds__(VB) void
+reduce_slots_kernel(const double * __restrict__ part, int nb, SlotList sl, double * __restrict__ red)
+{
+	const double v = sum_partials(part, sl.s[blockIdx.x], nb);
+	if (threadIdx.x == 0)
+		red[blockIdx.x] = v;
+}
+
+__global__ void
+scatter_slots_kernel(double * __restrict__ part, SlotList sl, const double * __restrict__ red)
+{
+	if (threadIdx.x < sl.n)
+		part[(long) sl.s[threadIdx.x] * MAX_PART] = red[threadIdx.x];
 }
 
 #define GRID_STRIDE(i, m) for (long i = (long) blockIdx.x * VB + threadIdx.x; i < (m); i += (long) gridDim.x * VB)
@@ -296,7 +318,7 @@ cg_direction_kernel(const SolverState * __restrict__ st_p, SolverState * __restr
 		if (blockIdx.x == 0 && threadIdx.x == 0)
 		{
 			*st_next = st;
-			post_progress(host_progress, it + 1, 1);
+			post_progress(host_progress, it + 1, st.k);
 		}
 		return;
 	}
@@ -315,7 +337,7 @@ cg_direction_kernel(const SolverState * __restrict__ st_p, SolverState * __restr
 			nx.k = st.k + 1;
 			nx.done = nx.err < nx.eps;
 			*st_next = nx;
-			post_progress(host_progress, it + 1, nx.done);
+			post_progress(host_progress, it + 1, nx.done ? nx.k : -1);
 		}
 	}
 }
@@ -444,7 +466,7 @@ bicg_direction_kernel(const SolverState * __restrict__ st_p, SolverState * __res
 			nx.err = sqrt(rr);
 			nx.k = st.k + 1;
 			*st_next = nx;
-			post_progress(host_progress, it + 1, 0);
+			post_progress(host_progress, it + 1, -1);
 		}
 	}
 }
@@ -475,7 +497,7 @@ struct DeviceBuffers {
 // Jacobi preconditioner: the first stored entry of row i whose column is i (bench_cg.cpp:114-134).
 template <typename T>
 static long
-jacobi_diagonal(const int32_t * row_ptr, const int32_t * col, const double * val, long m, T * K)
+jacobi_diagonal(const int32_t * row_ptr, const int32_t * col, const double * val, long m, long row_offset, T * K)
 {
 	long bad = -1;
 	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static)
@@ -483,7 +505,7 @@ jacobi_diagonal(const int32_t * row_ptr, const int32_t * col, const double * val
 	{
 		T k = 0;
 		for (long j = row_ptr[i]; j < row_ptr[i + 1]; j++)
-			if (col[j] == i)
+			if (col[j] == i + row_offset)
 			{
 				k = (T) val[j];
 				break;
@@ -507,17 +529,18 @@ jacobi_diagonal(const int32_t * row_ptr, const int32_t * col, const double * val
 
 template <typename T>
 static int
-solve(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t * col, const double * val, const void * b_host,
-		void * x_host, long max_iterations, double * history_host, spmv_mi355x_solver_info * info)
+solve(int method, spmv_mi355x_matrix * A, const spmv_mi355x_dist_ops * dist, long m_arg, const int32_t * row_ptr, const int32_t * col,
+		const double * val, const void * b_host, void * x_host, long max_iterations, double * history_host,
+		spmv_mi355x_solver_info * info)
 {
 	const auto t_start = std::chrono::steady_clock::now();
-	const long m = spmv_mi355x_rows(A);
+	const long m = dist ? m_arg : spmv_mi355x_rows(A);
 	hipStream_t stream = nullptr;
 	DeviceBuffers buf;
 	const size_t vb = (size_t) m * sizeof(T);
 
 	std::vector<T> K_host((size_t) std::max<long>(m, 1));
-	const long bad = jacobi_diagonal<T>(row_ptr, col, val, m, K_host.data());
+	const long bad = jacobi_diagonal<T>(row_ptr, col, val, m, dist ? dist->row_offset : 0, K_host.data());
 	if (bad >= 0)
 	{
 		set_error("bad K, zero in diagonal (row %ld)", bad);
@@ -543,7 +566,7 @@ solve(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t
 	HIP_TRY(hipHostMalloc(&buf.pinned, 2 * sizeof(long), hipHostMallocMapped | hipHostMallocCoherent));
 	volatile long * progress = (volatile long *) buf.pinned;          // [0] iterations finished, [1] break flag
 	progress[0] = 0;
-	progress[1] = 0;
+	progress[1] = -1;
 	long * progress_dev = nullptr;
 	HIP_TRY(hipHostGetDevicePointer((void **) &progress_dev, buf.pinned, 0));
 
@@ -558,14 +581,38 @@ solve(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t
 	long spmv_calls = 0;
 	auto spmv = [&](const T * in, T * out) {
 		spmv_calls++;
+		if (dist)
+		{
+			if (dist->spmv(dist->ctx, in, out))
+			{
+				set_error("solver: the caller's distributed spmv callback failed");
+				return 1;
+			}
+			return 0;
+		}
 		return spmv_mi355x_spmv_device_async(A, in, out, 0, stream);
+	};
+	// single GPU: consumers re-reduce the nb per-block partials themselves. Distributed: the listed slots are reduced,
+	// summed over the ranks by the caller's collective and put back as ONE partial; consumers then read nbc = 1 partial.
+	const int nbc = dist ? 1 : nb;
+	auto global_reduce = [&](SlotList sl) {
+		if (!dist)
+			return 0;
+		hipLaunchKernelGGL(reduce_slots_kernel, dim3(sl.n), block, 0, stream, part, nb, sl, dist->reduce_buf_dev);
+		if (dist->allreduce_sum(dist->ctx, dist->reduce_buf_dev, sl.n))
+		{
+			set_error("solver: the caller's all-reduce callback failed");
+			return 1;
+		}
+		hipLaunchKernelGGL(scatter_slots_kernel, one, dim3(WAVE), 0, stream, part, sl, dist->reduce_buf_dev);
+		return 0;
 	};
 	// |b - A x|^2 into partial A, r_explicit = b - A x
 	auto explicit_residual = [&](const T * xx) {
 		if (spmv(xx, Ap))
 			return 1;
 		hipLaunchKernelGGL((residual_kernel<T>), grid, block, 0, stream, b, Ap, r_explicit, m, part);
-		return 0;
+		return global_reduce({1, {P_A, 0, 0}});
 	};
 
 	// r0 = b - A x0
@@ -575,7 +622,8 @@ solve(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t
 		hipLaunchKernelGGL((cg_init_kernel<T>), grid, block, 0, stream, r, K, p, m, part);
 	else
 		hipLaunchKernelGGL((bicg_init_kernel<T>), grid, block, 0, stream, r, K, r0, p, y, m);
-	hipLaunchKernelGGL(init_state_kernel, one, block, 0, stream, st, nb, method, part);
+	ABI_TRY(global_reduce({3, {P_A, P_B, P_C}}));
+	hipLaunchKernelGGL(init_state_kernel, one, block, 0, stream, st, nbc, method, part);
 	HIP_TRY(hipGetLastError());
 
 	const bool debug = getenv("SPMV_MI355X_SOLVER_DEBUG") != nullptr;
@@ -604,33 +652,43 @@ solve(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t
 				__builtin_ia32_pause();
 			}
 			t_spin += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
-			if (progress[1])
+			// stop rule that every rank of a distributed solve evaluates identically: only what the device had posted by
+			// iteration it - POLL counts (the wait above guarantees it is visible), never "whatever is visible now"
+			const long broke_at = progress[1];
+			if (broke_at >= 0 && broke_at <= it - POLL)
 				break;
 		}
 		SolverState * cur = st + (it & 1), * nxt = st + ((it + 1) & 1);
 		if (it > 0 && it % RESTART_K == 0)
 		{
 			ABI_TRY(explicit_residual(x));
-			hipLaunchKernelGGL((explicit_kernel<T>), grid, block, 0, stream, cur, x, x_best, r_explicit, r, p, K, m, nb,
+			hipLaunchKernelGGL((explicit_kernel<T>), grid, block, 0, stream, cur, x, x_best, r_explicit, r, p, K, m, nbc,
 					method == 0, 0, part);
-			hipLaunchKernelGGL(explicit_fin_kernel, one, block, 0, stream, cur, nb, method == 0, 0, part);
+			if (method == 0)
+				ABI_TRY(global_reduce({1, {P_C, 0, 0}}));             // z.r of a restart (stale and unread otherwise)
+			hipLaunchKernelGGL(explicit_fin_kernel, one, block, 0, stream, cur, nbc, method == 0, 0, part);
 		}
 		if (method == 0)
 		{
 			ABI_TRY(spmv(p, Ap));
 			hipLaunchKernelGGL((cg_dot_kernel<T>), grid, block, 0, stream, cur, p, Ap, m, history, it, part);
-			hipLaunchKernelGGL((cg_update_kernel<T>), grid, block, 0, stream, cur, x, r, p, Ap, K, m, nb, part);
-			hipLaunchKernelGGL((cg_direction_kernel<T>), grid, block, 0, stream, cur, nxt, r, p, K, m, nb, part, it, progress_dev);
+			ABI_TRY(global_reduce({1, {P_A, 0, 0}}));
+			hipLaunchKernelGGL((cg_update_kernel<T>), grid, block, 0, stream, cur, x, r, p, Ap, K, m, nbc, part);
+			ABI_TRY(global_reduce({2, {P_D, P_E, 0}}));
+			hipLaunchKernelGGL((cg_direction_kernel<T>), grid, block, 0, stream, cur, nxt, r, p, K, m, nbc, part, it, progress_dev);
 		}
 		else
 		{
 			ABI_TRY(spmv(y, v));
 			hipLaunchKernelGGL((bicg_dot_kernel<T>), grid, block, 0, stream, cur, r0, v, m, history, it, part);
-			hipLaunchKernelGGL((bicg_s_kernel<T>), grid, block, 0, stream, cur, r, v, K, s, z, m, nb, part);
+			ABI_TRY(global_reduce({1, {P_A, 0, 0}}));
+			hipLaunchKernelGGL((bicg_s_kernel<T>), grid, block, 0, stream, cur, r, v, K, s, z, m, nbc, part);
 			ABI_TRY(spmv(z, Ap));                                // t = A z
 			hipLaunchKernelGGL((bicg_omega_kernel<T>), grid, block, 0, stream, Ap, s, K, m, part);
-			hipLaunchKernelGGL((bicg_update_kernel<T>), grid, block, 0, stream, cur, s, Ap, y, z, r0, r, x, m, nb, part);
-			hipLaunchKernelGGL((bicg_direction_kernel<T>), grid, block, 0, stream, cur, nxt, r, v, K, p, y, m, nb, part, it,
+			ABI_TRY(global_reduce({2, {P_B, P_C, 0}}));
+			hipLaunchKernelGGL((bicg_update_kernel<T>), grid, block, 0, stream, cur, s, Ap, y, z, r0, r, x, m, nbc, part);
+			ABI_TRY(global_reduce({2, {P_D, P_E, 0}}));
+			hipLaunchKernelGGL((bicg_direction_kernel<T>), grid, block, 0, stream, cur, nxt, r, v, K, p, y, m, nbc, part, it,
 					progress_dev);
 		}
 	}
@@ -649,16 +707,16 @@ solve(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t
 	// final explicit residual of x, promotion of x_best (bench_cg.cpp:288-306); runs after a break too
 	SolverState * fin = st + (it & 1);
 	ABI_TRY(explicit_residual(x));
-	hipLaunchKernelGGL((explicit_kernel<T>), grid, block, 0, stream, fin, x, x_best, r_explicit, r, p, K, m, nb, 0, 1, part);
-	hipLaunchKernelGGL(explicit_fin_kernel, one, block, 0, stream, fin, nb, 0, 1, part);
+	hipLaunchKernelGGL((explicit_kernel<T>), grid, block, 0, stream, fin, x, x_best, r_explicit, r, p, K, m, nbc, 0, 1, part);
+	hipLaunchKernelGGL(explicit_fin_kernel, one, block, 0, stream, fin, nbc, 0, 1, part);
 	// the harness's own check of the returned vector: error = |b - A x_best| (bench_cg.cpp:412-418)
 	ABI_TRY(explicit_residual(x_best));
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(x_host, x_best, vb, hipMemcpyDeviceToHost, stream));
 	SolverState st_host;
-	std::vector<double> part_host((size_t) nb);
+	std::vector<double> part_host((size_t) nbc);
 	HIP_TRY(hipMemcpyAsync(&st_host, fin, sizeof(SolverState), hipMemcpyDeviceToHost, stream));
-	HIP_TRY(hipMemcpyAsync(part_host.data(), part + (long) P_A * MAX_PART, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipMemcpyAsync(part_host.data(), part + (long) P_A * MAX_PART, sizeof(double) * nbc, hipMemcpyDeviceToHost, stream));
 	if (history)
 		HIP_TRY(hipMemcpyAsync(history_host, history, sizeof(double) * 3 * (size_t) max_iterations, hipMemcpyDeviceToHost, stream));
 	HIP_TRY(hipStreamSynchronize(stream));
@@ -719,13 +777,59 @@ solve_entry(int method, spmv_mi355x_matrix * A, const int32_t * row_ptr, const i
 	}
 	HIP_TRY(hipSetDevice(spmv_mi355x_device(A)));
 	if (spmv_mi355x_precision(A) == SPMV_MI355X_F32)
-		return solve<float>(method, A, row_ptr, col, val, b_host, x_host, max_iterations, history_host, info);
-	return solve<double>(method, A, row_ptr, col, val, b_host, x_host, max_iterations, history_host, info);
+		return solve<float>(method, A, nullptr, 0, row_ptr, col, val, b_host, x_host, max_iterations, history_host, info);
+	return solve<double>(method, A, nullptr, 0, row_ptr, col, val, b_host, x_host, max_iterations, history_host, info);
+}
+
+static int
+solve_dist_entry(int method, const spmv_mi355x_dist_ops * ops, int precision, long m_local, const int32_t * row_ptr, const int32_t * col,
+		const double * val, const void * b_host, void * x_host, long max_iterations, double * history_host,
+		spmv_mi355x_solver_info * info)
+{
+	if (!ops || ops->struct_size < sizeof(spmv_mi355x_dist_ops) || !ops->spmv || !ops->allreduce_sum || !ops->reduce_buf_dev)
+	{
+		set_error("distributed solver: ops incomplete (struct_size, spmv, allreduce_sum and reduce_buf_dev are required)");
+		return 1;
+	}
+	if (!row_ptr || !b_host || !x_host || m_local < 0 || max_iterations < 0 || (row_ptr[m_local] > 0 && (!col || !val)))
+	{
+		set_error("distributed solver: bad argument");
+		return 1;
+	}
+	if (info && info->struct_size < 8)
+	{
+		set_error("solver: info->struct_size not set");
+		return 1;
+	}
+	if (precision == SPMV_MI355X_F32)
+		return solve<float>(method, nullptr, ops, m_local, row_ptr, col, val, b_host, x_host, max_iterations, history_host, info);
+	if (precision == SPMV_MI355X_F64)
+		return solve<double>(method, nullptr, ops, m_local, row_ptr, col, val, b_host, x_host, max_iterations, history_host, info);
+	set_error("unknown precision %d", precision);
+	return 1;
 }
 
 }  // namespace spmv
 
 extern "C" {
+
+int
+spmv_mi355x_pcg_dist(const spmv_mi355x_dist_ops * ops, int precision, long m_local, const int32_t * row_ptr_local,
+		const int32_t * col_idx_global, const double * values_fp64, const void * b_local_host, void * x_local_host,
+		long max_iterations, double * history_out, spmv_mi355x_solver_info * info)
+{
+	return spmv::solve_dist_entry(0, ops, precision, m_local, row_ptr_local, col_idx_global, values_fp64, b_local_host, x_local_host,
+			max_iterations, history_out, info);
+}
+
+int
+spmv_mi355x_pbicgstab_dist(const spmv_mi355x_dist_ops * ops, int precision, long m_local, const int32_t * row_ptr_local,
+		const int32_t * col_idx_global, const double * values_fp64, const void * b_local_host, void * x_local_host,
+		long max_iterations, double * history_out, spmv_mi355x_solver_info * info)
+{
+	return spmv::solve_dist_entry(1, ops, precision, m_local, row_ptr_local, col_idx_global, values_fp64, b_local_host, x_local_host,
+			max_iterations, history_out, info);
+}
 
 int
 spmv_mi355x_pcg(spmv_mi355x_matrix * A, const int32_t * row_ptr, const int32_t * col_idx, const double * values_fp64,

@@ -1143,6 +1143,19 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 }
 
 int
+spmv_mi355x_copy_device_async(void * dst, const void * src, long bytes, void * hip_stream)
+{
+	if (bytes < 0 || (bytes > 0 && (!dst || !src)))
+	{
+		set_error("copy_device_async: bad argument");
+		return 1;
+	}
+	if (bytes)
+		HIP_TRY(hipMemcpyAsync(dst, src, (size_t) bytes, hipMemcpyDeviceToDevice, (hipStream_t) hip_stream));
+	return 0;
+}
+
+int
 spmv_mi355x_time_device(spmv_mi355x_matrix * A, const void * x, void * y, int iters, void * hip_stream, double * ms_out)
 {
 	hipStream_t st = (hipStream_t) hip_stream;

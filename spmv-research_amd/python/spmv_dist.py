@@ -99,3 +99,81 @@ class TrimmedExchange:
     def start(self):
         ops = self.ops()
         return self.dist.batch_isend_irecv(ops) if ops else []
+
+
+class DistributedSolver:
+    """Row-partitioned Jacobi-PCG / BiCGSTAB (the multi-GPU form of bench_cg.cpp / bench_bicg.cpp, SURVEY §8 rows e + f3).
+
+    The solver itself is the device-resident C-ABI one (csrc/solvers.hip); this class supplies what needs the communicator:
+    the SpMV callback = copy of the rank's vector slice into the padded exchange buffer + in-place all_gather_into_tensor
+    (RCCL over xGMI) + the local SpMV launch, and the all-reduce of the dot-product partials. `dist` is torch.distributed
+    with an initialised process group (nccl on the GPUs of a node; gloo for the single-GPU rehearsal and the tests)."""
+
+    def __init__(self, dist, torch, block, offsets, rank, world, fmt="sell_c_sigma", dtype=np.float64, **opts):
+        import ctypes as C
+        import spmv_mi355x as E
+        self.dist, self.torch, self.E, self.C = dist, torch, E, C
+        self.rank, self.world = rank, world
+        self.offsets = np.asarray(offsets, np.int64)
+        self.dtype = np.dtype(dtype)
+        self.m = int(block["m"])
+        self.block = block                                   # local CSR with GLOBAL columns: the Jacobi diagonal is read from it
+        self.padded = padded_len(self.offsets)
+        cols = np.ascontiguousarray(block["col_idx"]).copy()
+        to_padded_columns(cols, self.offsets, self.padded)
+        self.M = E.Matrix(block["row_ptr"], cols, block["values"], self.m, world * self.padded, fmt, dtype, **opts)
+        td = torch.float64 if self.dtype == np.float64 else torch.float32
+        self.x_full = torch.zeros(world * self.padded, dtype=td, device="cuda")
+        self.x_own = self.x_full[rank * self.padded:(rank + 1) * self.padded]
+        self.red = torch.zeros(8, dtype=torch.float64, device="cuda")
+        self.calls = dict(spmv=0, allreduce=0)
+        vb = self.dtype.itemsize
+
+        def spmv_cb(_ctx, in_ptr, out_ptr):
+            try:
+                E._check(E.lib().spmv_mi355x_copy_device_async(C.c_void_p(self.x_own.data_ptr()), C.c_void_p(in_ptr),
+                                                              C.c_long(self.m * vb), None))
+                if world > 1:
+                    dist.all_gather_into_tensor(self.x_full, self.x_own)
+                self.M.spmv_device(self.x_full.data_ptr(), out_ptr, 0, 0)
+                self.calls["spmv"] += 1
+                return 0
+            except Exception as e:                           # never let an exception cross the C frame
+                self.error = e
+                return 1
+
+        def allreduce_cb(_ctx, _buf, count):
+            try:
+                if world > 1:
+                    dist.all_reduce(self.red[:count])
+                self.calls["allreduce"] += 1
+                return 0
+            except Exception as e:
+                self.error = e
+                return 1
+
+        self.error = None
+        self._cbs = (E.SPMV_CB(spmv_cb), E.ALLREDUCE_CB(allreduce_cb))      # keep the thunks alive
+        self.ops = E.DistOps()
+        self.ops.struct_size = C.sizeof(E.DistOps)
+        self.ops.row_offset = int(self.offsets[rank])
+        self.ops.spmv = self._cbs[0]
+        self.ops.allreduce_sum = self._cbs[1]
+        self.ops.reduce_buf_dev = self.red.data_ptr()
+        self.ops.ctx = None
+
+    def _solve(self, method, b_local, max_iterations, history):
+        b = self.block
+        try:
+            return self.E.solve_distributed(method, self.ops, self.dtype, self.m, b["row_ptr"], b["col_idx"], b["values"], b_local,
+                                            max_iterations, history)
+        except Exception:
+            if self.error is not None:
+                raise self.error
+            raise
+
+    def pcg(self, b_local, max_iterations, history=True):
+        return self._solve("pcg", b_local, max_iterations, history)
+
+    def pbicgstab(self, b_local, max_iterations, history=True):
+        return self._solve("pbicgstab", b_local, max_iterations, history)

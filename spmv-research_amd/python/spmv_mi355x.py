@@ -37,7 +37,8 @@ SYMBOLS = [
     "spmv_mi355x_upload_x", "spmv_mi355x_download_y", "spmv_mi355x_spmv_device_async", "spmv_mi355x_time_device",
     "spmv_mi355x_kernel_info", "spmv_mi355x_x_device", "spmv_mi355x_y_device", "spmv_mi355x_sell_layout",
     "spmv_mi355x_merge_tiles", "spmv_mi355x_free", "spmv_mi355x_precision", "spmv_mi355x_device",
-    "spmv_mi355x_pcg", "spmv_mi355x_pbicgstab",
+    "spmv_mi355x_pcg", "spmv_mi355x_pbicgstab", "spmv_mi355x_pcg_dist", "spmv_mi355x_pbicgstab_dist",
+    "spmv_mi355x_copy_device_async",
 ]
 
 _lib = None
@@ -100,6 +101,36 @@ class SolverInfo(C.Structure):
     _fields_ = [("struct_size", C.c_uint), ("iterations", C.c_long), ("error", C.c_double), ("error_best", C.c_double),
                 ("eps", C.c_double), ("eps_counter", C.c_double), ("restarts", C.c_long), ("spmv_calls", C.c_long),
                 ("seconds", C.c_double)]
+
+
+SPMV_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+
+class DistOps(C.Structure):
+    """spmv_mi355x_dist_ops (include/spmv_mi355x.h)"""
+    _fields_ = [("struct_size", C.c_uint), ("row_offset", C.c_long), ("spmv", SPMV_CB), ("allreduce_sum", ALLREDUCE_CB),
+                ("reduce_buf_dev", C.c_void_p), ("ctx", C.c_void_p)]
+
+
+def solve_distributed(method, ops, dtype, m_local, row_ptr, col_idx, values, b, max_iterations, history=True):
+    """spmv_mi355x_pcg_dist / spmv_mi355x_pbicgstab_dist: returns the same dict as Matrix.pcg for the LOCAL slice of x."""
+    dtype = np.dtype(dtype)
+    row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+    col_idx = np.ascontiguousarray(col_idx, np.int32)
+    values = np.ascontiguousarray(values, np.float64)
+    b = np.ascontiguousarray(b, dtype)
+    x = np.zeros(max(m_local, 1), dtype)
+    hist = np.zeros((max(max_iterations, 1), 3), np.float64) if history else None
+    info = SolverInfo()
+    info.struct_size = C.sizeof(SolverInfo)
+    fn = lib().spmv_mi355x_pcg_dist if method == "pcg" else lib().spmv_mi355x_pbicgstab_dist
+    _check(fn(C.byref(ops), F64 if dtype == np.float64 else F32, C.c_long(m_local), _p(row_ptr), _p(col_idx), _p(values),
+              _p(b), _p(x), C.c_long(max_iterations), _p(hist) if history else None, C.byref(info)))
+    out = {k: getattr(info, k) for k, _ in SolverInfo._fields_ if k != "struct_size"}
+    out["x"] = x[:m_local]
+    out["history"] = hist[:info.iterations] if history else None
+    return out
 
 
 class Matrix:

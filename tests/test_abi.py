@@ -33,7 +33,7 @@ def test_opts_struct_layout_matches_header(tmp_path):
     import subprocess
     import spmv_mi355x as E
     lines = []
-    for cname, cls in (("spmv_mi355x_opts", E.Opts), ("spmv_mi355x_solver_info", E.SolverInfo)):
+    for cname, cls in (("spmv_mi355x_opts", E.Opts), ("spmv_mi355x_solver_info", E.SolverInfo), ("spmv_mi355x_dist_ops", E.DistOps)):
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
         for fname, _ in cls._fields_:
             lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
@@ -42,7 +42,7 @@ def test_opts_struct_layout_matches_header(tmp_path):
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
-    for cname, cls in (("spmv_mi355x_opts", E.Opts), ("spmv_mi355x_solver_info", E.SolverInfo)):
+    for cname, cls in (("spmv_mi355x_opts", E.Opts), ("spmv_mi355x_solver_info", E.SolverInfo), ("spmv_mi355x_dist_ops", E.DistOps)):
         assert int(got[cname]) == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
