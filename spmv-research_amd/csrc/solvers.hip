@@ -118,7 +118,7 @@ reduce_slots_kernel(const double * __restrict__ part, int nb, SlotList sl, doubl
 __global__ void
 scatter_slots_kernel(double * __restrict__ part, SlotList sl, const double * __restrict__ red)
 {
-	if (threadIdx.x < sl.n)
+	if ((int) threadIdx.x < sl.n)
 		part[(long) sl.s[threadIdx.x] * MAX_PART] = red[threadIdx.x];
 }
 
