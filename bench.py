@@ -94,6 +94,27 @@ def load_traffic(workload, fmt, dtype, kernel):
     return best
 
 
+class QuietStdout:
+    """Send the process's fd 1 to /dev/null for a block (C-level printf of the reference library included)."""
+
+    def __enter__(self):
+        import ctypes
+        self.libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        self.saved = os.dup(1)
+        dn = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(dn, 1)
+        os.close(dn)
+        return self
+
+    def __exit__(self, *exc):
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def cpu_share():
     """cores this job may use: the cgroup CPU quota when there is one, else the affinity mask"""
     n = len(os.sched_getaffinity(0))
@@ -422,7 +443,7 @@ def main():
         "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t_conv, 2)},
     }
 
-    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1): the oracle = port
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1): reference build, else the port
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as orc                                  # checker only: timed beside the GPU, never shipped
@@ -436,10 +457,29 @@ def main():
             rs = lm
             sample = f"whole {workload} twin ({lnnz} nnz)"
         snnz = int(rp[rs])
-        tb = orc.time_csr_spmv(rp[:rs + 1], ci[:snnz], va[:snnz], x_host.astype(np.float64), cores,
-                               min_loops=5, min_runtime=args.cpu_baseline_seconds)
+        # Preferred baseline: the GENUINE reference CPU CSR backend (spmv_kernels/csr.cpp compiled in place by oracle/Makefile
+        # into oracle/_ref, which travels with the repo) under the reference driver's timing protocol; where that library
+        # is absent or does not load on this CPU, the oracle's port of the same path.
+        kind, tb, ys = "port", None, None
+        try:
+            import refdrv
+            flavour = "native" if refdrv.available("csr", "d", "native") else "v3"
+            prec = "f" if dts == "f32" else "d"
+            if refdrv.available("csr", prec, flavour):
+                with QuietStdout():                                   # the reference prints to C stdout; ours carries ONE JSON line
+                    rb = refdrv.RefBackend("csr", prec, flavour, threads=cores)
+                    rb.csr_to_format(rp[:rs + 1], ci[:snnz], va[:snnz], rs, n)
+                    ys = rb.spmv(x_host).astype(np.float64)
+                    tb = rb.time_spmv(x_host, min_loops=5, min_runtime=args.cpu_baseline_seconds)
+                kind = "reference"
+        except Exception as e:                                        # e.g. an AVX-512 build on a CPU without it
+            print(f"[bench] reference CPU backend unavailable ({e}); timing the oracle port", file=sys.stderr)
+            tb = None
+        if tb is None:
+            tb = orc.time_csr_spmv(rp[:rs + 1], ci[:snnz], va[:snnz], x_host.astype(np.float64), cores,
+                                   min_loops=5, min_runtime=args.cpu_baseline_seconds)
+            ys = np.asarray(tb["y"], np.float64)
         # the baseline must have done the work: its y agrees with the GPU's on the sampled rows
-        ys = np.asarray(tb["y"], np.float64)
         chk = [i for i in samp if i < rs]
         if chk:
             dmax = float(np.max(np.abs(ys[chk] - yh[chk]) / np.maximum(np.abs(yh[chk]), 1e-300)))
@@ -451,9 +491,9 @@ def main():
         except OSError:
             pass
         result["cpu_baseline"] = {"value": round(2.0 * snnz / tb["median"] / 1e9, 3), "unit": "GFLOP/s",
-                                  "cores": cores, "cpu_model": cpu_model, "kind": "port", "sample": sample,
+                                  "cores": cores, "cpu_model": cpu_model, "kind": kind, "sample": sample,
                                   "median_s": tb["median"], "loops": tb["loops"],
-                                  "gbps": round(algorithmic_bytes(rs, n, snnz, 8) / tb["median"] / 1e9, 2)}
+                                  "gbps": round(algorithmic_bytes(rs, n, snnz, (4 if dts == "f32" else 8) if kind == "reference" else 8) / tb["median"] / 1e9, 2)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
