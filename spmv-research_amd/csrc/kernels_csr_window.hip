@@ -137,11 +137,87 @@ window_rows(const int * __restrict__ row_ptr, const int * __restrict__ col, cons
 	}
 }
 
+
+// RPG consecutive rows of a lane group in flight together (as csr_vector_multi_kernel), x from the LDS window. The row
+// pointers of the group's NEXT set of rows are loaded before the current set is consumed, so a set costs one exposed
+// global round trip (its index/value batches); the two-deep single-row pipeline of window_rows() exposes one per row.
+template <typename T, int G, int RPG, bool NT, bool LDSX>
+__device__ __forceinline__ void
+window_rows_multi(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
+		const T * __restrict__ x, const T * __restrict__ xs, T * __restrict__ y, int r0, int r1, int lo, int beta)
+{
+	constexpr int U = 4;
+	constexpr int NG = WIN_BLOCK / G;
+	static_assert(RPG + 1 <= G, "one lane per row pointer");
+	const int group = threadIdx.x / G;
+	const int lane = threadIdx.x % G;
+	int base = r0 + group * RPG;
+	int rp_mine = row_ptr[min(base + min(lane, RPG), r1)];
+	while (base < r1)
+	{
+		const int nbase = base + NG * RPG;
+		const int rp_next = row_ptr[min(nbase + min(lane, RPG), r1)];       // in flight while this set is consumed
+		int j[RPG], je[RPG];
+		T acc[RPG];
+		bool any = false;
+		#pragma unroll
+		for (int r = 0; r < RPG; r++)
+		{
+			j[r] = __shfl(rp_mine, r, G) + lane;
+			je[r] = __shfl(rp_mine, r + 1, G);
+			acc[r] = 0;
+			any |= j[r] < je[r];
+		}
+		while (any)
+		{
+			int c[RPG][U];
+			T v[RPG][U];
+			#pragma unroll
+			for (int r = 0; r < RPG; r++)
+				#pragma unroll
+				for (int u = 0; u < U; u++)
+				{
+					const bool ok = j[r] + u * G < je[r];
+					c[r][u] = ok ? ld_stream<NT>(col + j[r] + u * G) : -1;
+					v[r][u] = ok ? ld_stream<NT>(val + j[r] + u * G) : (T) 0;
+				}
+			any = false;
+			#pragma unroll
+			for (int r = 0; r < RPG; r++)
+			{
+				#pragma unroll
+				for (int u = 0; u < U; u++)
+				{
+					T xv;
+					if (LDSX)
+						xv = c[r][u] >= 0 ? xs[c[r][u] - lo] : (T) 0;
+					else
+						xv = c[r][u] >= 0 ? x[c[r][u]] : (T) 0;
+					acc[r] = c[r][u] >= 0 ? fma_t<T>(v[r][u], xv, acc[r]) : acc[r];
+				}
+				j[r] += U * G;
+				any |= j[r] < je[r];
+			}
+		}
+		T mine = 0;
+		#pragma unroll
+		for (int r = 0; r < RPG; r++)
+		{
+			const T total = group_reduce_sum<T, G>(acc[r]);
+			mine = lane == r ? total : mine;
+		}
+		if (lane < RPG && base + lane < r1)
+			y[base + lane] = beta ? y[base + lane] + mine : mine;
+		base = nbase;
+		rp_mine = rp_next;
+	}
+}
+
 template <typename T, int G, bool NT>
 __global__ __launch_bounds__(WIN_BLOCK) void
 csr_window_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
 		const T * __restrict__ x, T * __restrict__ y, int beta, const int * __restrict__ blk_row,
-		const int * __restrict__ blk_lo, const int * __restrict__ blk_w, XcdMap map)
+		const int * __restrict__ blk_lo, const int * __restrict__ blk_w, int multi_rows, XcdMap map)
 {
 	extern __shared__ __align__(16) unsigned char window_smem[];
 	T * xs = reinterpret_cast<T *>(window_smem);
@@ -155,7 +231,17 @@ csr_window_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col
 		for (int i = threadIdx.x; i < w; i += WIN_BLOCK)
 			xs[i] = x[lo + i];
 		__syncthreads();
-		window_rows<T, G, NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
+		// measured: several rows in flight win while the window is small (cant twin fp32 8.3 -> 7.1 us; many workgroups per
+		// CU), the two-deep single-row pipeline wins with ~50 KiB windows (pwtk twin fp32 18.6 vs 19.6 us)
+		if constexpr (G <= 32)
+		{
+			if (multi_rows)
+				window_rows_multi<T, G, (G <= 16 ? 4 : 2), NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
+			else
+				window_rows<T, G, NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
+		}
+		else
+			window_rows<T, G, NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
 	}
 	else
 		window_rows<T, G, NT, false>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
@@ -188,10 +274,10 @@ csr_window_launch(const int * row_ptr, const int * col, const void * val, const 
 	}
 	if (cfg.nt)
 		hipLaunchKernelGGL((csr_window_kernel<T, G, true>), dim3(grid), dim3(WIN_BLOCK), lds_bytes, stream, row_ptr, col,
-				(const T *) val, (const T *) x, (T *) y, cfg.beta, blk_row, blk_lo, blk_w, cfg.map);
+				(const T *) val, (const T *) x, (T *) y, cfg.beta, blk_row, blk_lo, blk_w, lds_bytes <= 16384 ? 1 : 0, cfg.map);
 	else
 		hipLaunchKernelGGL((csr_window_kernel<T, G, false>), dim3(grid), dim3(WIN_BLOCK), lds_bytes, stream, row_ptr, col,
-				(const T *) val, (const T *) x, (T *) y, cfg.beta, blk_row, blk_lo, blk_w, cfg.map);
+				(const T *) val, (const T *) x, (T *) y, cfg.beta, blk_row, blk_lo, blk_w, lds_bytes <= 16384 ? 1 : 0, cfg.map);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

@@ -792,7 +792,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 				// x window in LDS (kernels_csr_window.hip): nnz-balanced row blocks, a multiple of the 256 CUs. Forced by
 				// stream_mode 4; in auto mode adopted when (nearly) every block's window fits the LDS budget and rows are long
 				// enough to amortise the per-row butterfly (measured: pwtk twin fp32 22.1 -> 18.6 us; short-row / scattered
-				// matrices keep the other modes; fp64 windows of ~100 KiB and matrices under 8 M non-zeros did not gain).
+				// matrices keep the other modes; fp64 did not gain: the windows are twice as large and the register kernels are already at the coalesced-gather ceiling).
 				auto try_window = [&](bool force) -> int {
 					int G = R ? R : std::max(8, pick_lanes_per_row(mean));
 					if (G != 8 && G != 16 && G != 32 && G != 64)
@@ -834,7 +834,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 							max_w = std::max(max_w, b_w[b]);
 						}
 					}
-					if (!force && (with_window * 100 < nb * 95 || mean < 16 || !A->f32 || lnnz < (8L << 20)))
+					if (!force && (with_window * 100 < nb * 95 || mean < 16 || !A->f32 || lnnz < (2L << 20)))
 						return 0;
 					A->stream_mode = 4;
 					A->lanes_per_row = G;
