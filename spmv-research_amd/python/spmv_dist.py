@@ -64,23 +64,54 @@ def needed_ranges(col_idx_padded, padded, world):
     return H.column_ranges(col_idx_padded, padded, world)
 
 
-class TrimmedExchange:
-    """x exchange that moves only what each row block reads: rank p receives from rank q the contiguous sub-range
-    [lo, hi) of q's slice that p's columns touch — grouped RCCL send/recv (batch_isend_irecv) straight into the padded
-    x buffer, no packing. Degenerates to the full allgather when every rank reads everything. The range table is
-    agreed once (one small all_gather), so sends and receives always match."""
+MAX_RANGES = 4
 
-    def __init__(self, dist, x_full, padded, rank, world, lo, hi):
+
+def needed_subranges(col_idx_padded, padded, world, max_ranges=MAX_RANGES, min_gap=1 << 15):
+    """ranges[q, r] = (lo, hi): up to `max_ranges` disjoint sub-ranges of peer q's x slice that cover every column this
+    block references there (hi == lo: unused). One hull per peer is wasteful when a block touches two regions of a peer —
+    the nlpkkt240 twin's first row block needs 5.0 M entries of the second half of x but their hull spans 14.2 M (a few
+    constraint rows at the very end of the vector): the hull is cut at its largest gaps (>= min_gap entries)."""
+    touched = np.zeros(world * padded, bool)
+    touched[np.asarray(col_idx_padded, np.int64)] = True
+    out = np.zeros((world, max_ranges, 2), np.int64)
+    for q in range(world):
+        pos = np.flatnonzero(touched[q * padded:(q + 1) * padded])
+        if len(pos) == 0:
+            continue
+        gaps = np.diff(pos)
+        cut = np.sort(np.argsort(gaps)[::-1][:max_ranges - 1]) if len(gaps) else np.zeros(0, np.int64)
+        cut = cut[gaps[cut] >= min_gap]
+        starts = np.concatenate([[pos[0]], pos[cut + 1]])
+        ends = np.concatenate([pos[cut] + 1, [pos[-1] + 1]])
+        out[q, :len(starts), 0] = starts
+        out[q, :len(starts), 1] = ends
+    return out
+
+
+class TrimmedExchange:
+    """x exchange that moves only what each row block reads: rank p receives from rank q up to MAX_RANGES contiguous
+    sub-ranges of q's slice that cover the columns p touches — grouped RCCL send/recv (batch_isend_irecv) straight into the
+    padded x buffer, no packing. Degenerates to the full allgather when every rank reads everything. The range table is
+    agreed once (one small all_gather), so sends and receives always match. `lo`/`hi` (one hull per peer) or `ranges`
+    (needed_subranges) describe what THIS rank needs."""
+
+    def __init__(self, dist, x_full, padded, rank, world, lo=None, hi=None, ranges=None):
         import torch
         self.dist, self.x_full, self.padded, self.rank, self.world = dist, x_full, padded, rank, world
-        mine = torch.tensor(np.stack([lo, hi]).astype(np.int64))
+        if ranges is None:
+            ranges = np.zeros((world, 1, 2), np.int64)
+            ranges[:, 0, 0], ranges[:, 0, 1] = lo, hi
+        ranges = np.ascontiguousarray(ranges, np.int64)
+        self.R = ranges.shape[1]
+        mine = torch.tensor(ranges.reshape(-1))
         table = [torch.zeros_like(mine) for _ in range(world)]
         dev = x_full.device if dist.get_backend() == "nccl" else torch.device("cpu")
         mine_d = mine.to(dev)
         table = [t.to(dev) for t in table]
         dist.all_gather(table, mine_d)
-        self.need = np.stack([t.cpu().numpy() for t in table])            # need[p, 0/1, q]
-        self.recv_elems = int(sum(self.need[rank, 1, q] - self.need[rank, 0, q] for q in range(world) if q != rank))
+        self.need = np.stack([t.cpu().numpy().reshape(world, self.R, 2) for t in table])      # need[p, q, r] = (lo, hi)
+        self.recv_elems = int(sum((self.need[rank, q, :, 1] - self.need[rank, q, :, 0]).sum() for q in range(world) if q != rank))
         self._ops = None
 
     def ops(self):
@@ -89,20 +120,28 @@ class TrimmedExchange:
         for q in range(self.world):
             if q == r:
                 continue
-            lo, hi = int(self.need[r, 0, q]), int(self.need[r, 1, q])
-            if hi > lo:
-                out.append(P(d.irecv, self.x_full[q * pad + lo:q * pad + hi], q))
-            lo, hi = int(self.need[q, 0, r]), int(self.need[q, 1, r])
-            if hi > lo:
-                out.append(P(d.isend, self.x_full[r * pad + lo:r * pad + hi], q))
+            for k in range(self.R):
+                lo, hi = int(self.need[r, q, k, 0]), int(self.need[r, q, k, 1])
+                if hi > lo:
+                    out.append(P(d.irecv, self.x_full[q * pad + lo:q * pad + hi], q))
+            for k in range(self.R):
+                lo, hi = int(self.need[q, r, k, 0]), int(self.need[q, r, k, 1])
+                if hi > lo:
+                    out.append(P(d.isend, self.x_full[r * pad + lo:r * pad + hi], q))
         return out
 
     def start(self):
         # the op list (tensor views + peers) never changes: build it once — at 8 GPUs a step is a few hundred microseconds
-        # and re-slicing 14 views per step is host time on the critical path
+        # and re-slicing the views per step is host time on the critical path
         if self._ops is None:
             self._ops = self.ops()
         return self.dist.batch_isend_irecv(self._ops) if self._ops else []
+
+    def delivered(self):
+        """[(a, b)] absolute index ranges of x_full this rank receives (for validation)."""
+        return [(q * self.padded + int(self.need[self.rank, q, k, 0]), q * self.padded + int(self.need[self.rank, q, k, 1]))
+                for q in range(self.world) if q != self.rank for k in range(self.R)
+                if self.need[self.rank, q, k, 1] > self.need[self.rank, q, k, 0]]
 
 
 class DistributedSolver:

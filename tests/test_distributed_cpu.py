@@ -58,6 +58,17 @@ def _worker(rank, world, port, q):
         y_trim = orc.csr_spmv(blk["row_ptr"], blk["col_idx"], blk["values"], x_trim.numpy())
         y_full = orc.csr_spmv(blk["row_ptr"], blk["col_idx"], blk["values"], xp)
         np.testing.assert_array_equal(y_trim, y_full)
+        # several sub-ranges per peer (hull cut at its largest gaps): never more data than the hull, same result
+        sub = D.needed_subranges(blk["col_idx"], padded, world, min_gap=8)
+        x_sub = torch.zeros(world * padded, dtype=torch.float64)
+        x_sub[rank * padded:rank * padded + (r1 - r0)] = torch.from_numpy(x[r0:r1])
+        ex2 = D.TrimmedExchange(dist, x_sub, padded, rank, world, ranges=sub)
+        for req in ex2.start():
+            req.wait()
+        assert ex2.recv_elems <= ex.recv_elems
+        for a, b in ex2.delivered():
+            np.testing.assert_array_equal(x_sub[a:b].numpy(), xp[a:b])
+        np.testing.assert_array_equal(orc.csr_spmv(blk["row_ptr"], blk["col_idx"], blk["values"], x_sub.numpy()), y_full)
         ypad = torch.zeros(padded, dtype=torch.float64)             # validation only, not on the data path
         ypad[:r1 - r0] = torch.from_numpy(y)
         ys = [torch.zeros(padded, dtype=torch.float64) for _ in range(world)]
