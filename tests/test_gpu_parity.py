@@ -397,3 +397,40 @@ def test_driver_keep_symmetry_mode(eng):
         row = r.stderr.strip().splitlines()[-1].split(",")
         assert int(row[4]) == info["sym_nnz"] and int(row[5]) == 1          # csr_nnz = stored triangle, symmetry flag
         assert float(row[22]) < 1e-12                                       # spmv_max_ae against the symmetric quad gold
+
+
+# ---- directly against the GENUINE reference build (oracle/_ref travels with the repo), not through the restatement ----------
+
+def test_gpu_kernels_against_the_reference_build_on_random_matrices(eng):
+    """Same inputs into the reference CPU CSR backend (spmv_kernels/csr.cpp compiled in place) and into the GPU kernels:
+    bit-identical for the row-sequential kernels, reordering tolerance for the others."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import refdrv
+    flavour = "native" if refdrv.available("csr", "d", "native") else "v3"
+    if not refdrv.available("csr", "d", flavour):
+        pytest.skip("oracle/_ref not present")
+    refs = {np.float64: refdrv.RefBackend("csr", "d", flavour, threads=3), np.float32: refdrv.RefBackend("csr", "f", flavour, threads=3)}
+    rng = np.random.default_rng(99)
+    for trial in range(12):
+        kind = ("powerlaw", "short", "regular")[trial % 3]
+        m = int(rng.integers(100, 20000))
+        n = int(rng.integers(100, 20000))
+        rp, ci, a = synth(rng, m, n, kind)
+        x = rng.uniform(-1, 1, n)
+        absrow = None
+        for dtype, ref in refs.items():
+            ref.csr_to_format(rp, ci, a, m, n)
+            y_ref = ref.spmv(x)
+            if absrow is None:
+                refs[np.float64].csr_to_format(rp, ci, np.abs(a), m, n)
+                absrow = refs[np.float64].spmv(np.abs(x)).astype(np.float64)
+                ref.csr_to_format(rp, ci, a, m, n)
+                y_ref = ref.spmv(x)
+            for fmt, opts, exact in (("csr_scalar", {}, True), ("sell_c_sigma", {"sell_split": 1}, True), ("csr_vector", {}, False),
+                                     ("csr_stream", {}, False), ("csr_merge", {}, False), ("coo", {}, False)):
+                A = eng.Matrix(rp, ci, a, m, n, fmt, dtype, **opts)
+                check(A.spmv(x), y_ref, absrow, dtype, exact, f"vs reference build: trial {trial} {kind} {fmt} {np.dtype(dtype).name}")
+                A.close()
