@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "spmv-research_amd", "python"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 DEFAULT_FORMAT = {"nlpkkt240": "sell_c_sigma", "cant": "csr_vector", "pwtk": "csr_stream",
-                  "scircuit": "csr_stream", "soc-LiveJournal1": "csr_merge"}
+                  "scircuit": "csr_vector", "soc-LiveJournal1": "csr_merge"}
 DEFAULT_DTYPE = {"pwtk": "f32"}
 
 
