@@ -60,12 +60,12 @@ wave_max_i(int v)
 __device__ __forceinline__ long
 group_bytes(int md)
 {
-	return md == 1 ? 272 : md == 2 ? 528 : 1024;
+	return md == 0 ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
 }
 
 // pass 1: one wave per slice -> mode, number of value slots, number of index bytes
 __global__ __launch_bounds__(CV_BLOCK) void
-slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, const int * __restrict__ row_of_sorted, long m,
+slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, const int * __restrict__ row_of_sorted, long m, long n,
 		long num_slices, unsigned char * __restrict__ mode, int64_t * __restrict__ val_count, int64_t * __restrict__ idx_count)
 {
 	const long sl = ((long) blockIdx.x * CV_BLOCK + threadIdx.x) / WAVE;
@@ -80,8 +80,11 @@ slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, con
 		start = rp[o];
 		len = rp[o + 1] - start;
 	}
-	const int width = (wave_max_i(len) + 3) / 4 * 4;
+	const int maxlen = wave_max_i(len);
+	const int width = (maxlen + 3) / 4 * 4;
 	int maxdelta = 0;
+	// affine (mode 0): a full slice of equally long rows whose step-k columns are base_k + lane
+	int affine = ((sl + 1) * WAVE <= m && n >= WAVE && wave_min_i(len) == maxlen) ? 1 : 0;
 	for (int k = 0; k < width; k++)
 	{
 		const bool ok = k < len;
@@ -90,10 +93,12 @@ slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, con
 		const int hi = wave_max_i(ok ? c : -1);
 		if (hi >= 0)
 			maxdelta = max(maxdelta, hi - lo);
+		if (affine && k < maxlen)
+			affine = wave_min_i((ok && c == __shfl(c, 0, WAVE) + lane) ? 1 : 0);
 	}
 	if (lane == 0)
 	{
-		const int md = maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		const int md = affine ? 0 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
 		mode[sl] = (unsigned char) md;
 		val_count[sl] = (int64_t) width * WAVE;
 		idx_count[sl] = (int64_t) (width / 4) * group_bytes(md);
@@ -159,7 +164,7 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 			{
 				if (lane == 0)
 					reinterpret_cast<int *>(gp)[u] = base;
-				d[u] = (unsigned) (c - base);
+				d[u] = (unsigned) (c - base);               // unused by the affine mode (column = base + lane)
 			}
 			else
 				reinterpret_cast<int *>(gp)[u * WAVE + lane] = c;
@@ -197,9 +202,9 @@ struct Scratch {
 // Outputs (device, owned by the caller on success): row_of_sorted[m], desc[2*(slices+1)], idx[idx_bytes+1024], val[nnz_ext
 // + STREAM_SLACK] of the handle's precision. Host outputs: val_ptr (slices+1, for the tile map), mode counts, sizes.
 int
-sell_delta_convert_device(bool f32, long m, long nnz, long sigma, const int * rp_host, const int * ci_host, const double * va_host,
-		int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
-		std::vector<int64_t> & val_ptr_host, long mode_counts[3], int64_t * nnz_ext_out, int64_t * idx_bytes_out)
+sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
+		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
+		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out)
 {
 	const long num_slices = (m + WAVE - 1) / WAVE;
 	const long num_windows = (m + sigma - 1) / sigma;
@@ -256,7 +261,7 @@ sell_delta_convert_device(bool f32, long m, long nnz, long sigma, const int * rp
 	const unsigned slice_grid = (unsigned) (((num_slices + 1) * WAVE + CV_BLOCK - 1) / CV_BLOCK);
 	if (num_slices > 0)
 	{
-		hipLaunchKernelGGL(slice_shape_kernel, dim3(slice_grid), dim3(CV_BLOCK), 0, 0, rp, ci, row_of_sorted, m, num_slices, mode,
+		hipLaunchKernelGGL(slice_shape_kernel, dim3(slice_grid), dim3(CV_BLOCK), 0, 0, rp, ci, row_of_sorted, m, n_cols, num_slices, mode,
 				val_count, idx_count);
 		HIP_TRY(hipGetLastError());
 	}
@@ -278,9 +283,9 @@ sell_delta_convert_device(bool f32, long m, long nnz, long sigma, const int * rp
 		std::vector<unsigned char> mode_host((size_t) std::max<long>(num_slices, 1));
 		if (num_slices)
 			HIP_TRY(hipMemcpy(mode_host.data(), mode, (size_t) num_slices, hipMemcpyDeviceToHost));
-		mode_counts[0] = mode_counts[1] = mode_counts[2] = 0;
+		mode_counts[0] = mode_counts[1] = mode_counts[2] = mode_counts[3] = 0;
 		for (long sl = 0; sl < num_slices; sl++)
-			mode_counts[mode_host[sl] == 1 ? 0 : mode_host[sl] == 2 ? 1 : 2]++;
+			mode_counts[mode_host[sl] == 0 ? 3 : mode_host[sl] == 1 ? 0 : mode_host[sl] == 2 ? 1 : 2]++;
 	}
 
 	// 4. fill

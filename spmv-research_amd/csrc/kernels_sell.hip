@@ -146,7 +146,17 @@ __device__ __forceinline__ void
 sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * __restrict__ vp, int lane, const T * __restrict__ x, T & s)
 {
 	int c0, c1, c2, c3;
-	if constexpr (MODE == 1)
+	if constexpr (MODE == 0)
+	{
+		// affine slice: the 64 rows are consecutive AND step k of lane l is column base_k + l (a stencil diagonal): no per-lane
+		// index bytes at all, one scalar base per step
+		const sell_int4 base = *reinterpret_cast<const sell_int4 *>(gp);
+		c0 = base.x + lane;
+		c1 = base.y + lane;
+		c2 = base.z + lane;
+		c3 = base.w + lane;
+	}
+	else if constexpr (MODE == 1)
 	{
 		const sell_int4 base = *reinterpret_cast<const sell_int4 *>(gp);
 		const unsigned d = ld_stream<NT>(reinterpret_cast<const unsigned *>(gp + 16) + lane);
@@ -189,7 +199,7 @@ __device__ __forceinline__ T
 sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int groups, int lane, const T * __restrict__ x,
 		int g0 = 0, int gs = 1)
 {
-	constexpr int GB = MODE == 1 ? 272 : MODE == 2 ? 528 : 1024;     // bytes of one index group
+	constexpr int GB = MODE == 0 ? 16 : MODE == 1 ? 272 : MODE == 2 ? 528 : 1024;     // bytes of one index group
 	T s = 0;
 	int g = g0;
 	for (; g + gs < groups; g += 2 * gs)    // 8 steps in flight per trip
@@ -202,7 +212,7 @@ sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ v
 	return s;
 }
 
-// desc[2*s] = first value element of slice s, desc[2*s+1] = byte offset of its index block | mode (1, 2 or 4) in the low bits
+// desc[2*s] = first value element of slice s, desc[2*s+1] = byte offset of its index block | mode (0, 1, 2 or 4) in the low bits
 template <typename T, bool NT>
 __global__ __launch_bounds__(SELL_BLOCK) void
 sell_delta_kernel(const int64_t * __restrict__ desc, const unsigned char * __restrict__ idx, const T * __restrict__ val,
@@ -224,7 +234,9 @@ sell_delta_kernel(const int64_t * __restrict__ desc, const unsigned char * __res
 	const T * vp = val + v_off + lane;
 	const int groups = (int) ((v_next - v_off) / (4 * WAVE));
 	T s;
-	if (mode == 1)
+	if (mode == 0)
+		s = sell_delta_slice<T, 0, NT>(ip, vp, groups, lane, x);
+	else if (mode == 1)
 		s = sell_delta_slice<T, 1, NT>(ip, vp, groups, lane, x);
 	else if (mode == 2)
 		s = sell_delta_slice<T, 2, NT>(ip, vp, groups, lane, x);
@@ -266,7 +278,9 @@ sell_delta_split_kernel(const int64_t * __restrict__ desc, const unsigned char *
 		const unsigned char * ip = idx + (i_word & ~(int64_t) 15);
 		const T * vp = val + v_off + lane;
 		const int groups = (int) ((v_next - v_off) / (4 * WAVE));
-		if (mode == 1)
+		if (mode == 0)
+			s = sell_delta_slice<T, 0, NT>(ip, vp, groups, lane, x, w, S);
+		else if (mode == 1)
 			s = sell_delta_slice<T, 1, NT>(ip, vp, groups, lane, x, w, S);
 		else if (mode == 2)
 			s = sell_delta_slice<T, 2, NT>(ip, vp, groups, lane, x, w, S);

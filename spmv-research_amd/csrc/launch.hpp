@@ -65,9 +65,9 @@ int launch_sell_delta(bool f32, int waves_per_slice, const int64_t * desc, const
 		const void * x, void * y, int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
 // CSR -> SELL-64-sigma-delta on the GPU (convert_sell.hip); outputs are device arrays owned by the caller
-int sell_delta_convert_device(bool f32, long m, long nnz, long sigma, const int * rp_host, const int * ci_host, const double * va_host,
-		int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
-		std::vector<int64_t> & val_ptr_host, long mode_counts[3], int64_t * nnz_ext_out, int64_t * idx_bytes_out);
+int sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
+		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
+		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out);
 
 // ---- COO (kernels_coo.hip)
 int coo_wave_items(int items_per_lane);                                // entries per wavefront

@@ -67,7 +67,7 @@ struct spmv_mi355x_matrix {
 	int64_t * d_sell_desc = nullptr;
 	unsigned char * d_sell_idx = nullptr;
 	long sell_idx_bytes = 0;
-	long sell_mode_slices[3] = {0, 0, 0};  // slices stored with 8-bit / 16-bit / 32-bit indices
+	long sell_mode_slices[4] = {0, 0, 0, 0};  // slices stored with 8-bit / 16-bit / 32-bit indices / none (affine)
 	// COO
 	int coo_k = 0, coo_num_waves = 0;
 	int * d_rowind = nullptr;
@@ -296,7 +296,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 		std::vector<int64_t> val_ptr;
 		int64_t nnz_ext = 0, idx_bytes = 0;
 		void * d_val = nullptr;
-		if (sell_delta_convert_device(A->f32, m, A->nnz, sigma, rp, ci, va, &A->d_row_of_sorted, &A->d_sell_desc, &A->d_sell_idx,
+		if (sell_delta_convert_device(A->f32, m, A->n, A->nnz, sigma, rp, ci, va, &A->d_row_of_sorted, &A->d_sell_desc, &A->d_sell_idx,
 				&d_val, val_ptr, A->sell_mode_slices, &nnz_ext, &idx_bytes))
 			return 1;
 		A->d_val = d_val;
@@ -338,8 +338,16 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 			int o = row_of_sorted[i];
 			width = std::max<long>(width, rp[o + 1] - rp[o]);
 		}
+		const long maxlen = width;
 		width = (width + 3) / 4 * 4;
 		long maxdelta = 0;
+		// affine: a full slice of equally long rows whose step-k columns are base_k + lane (consecutive rows of a stencil)
+		bool affine = (sl + 1) * C <= m && A->n >= C;
+		for (long i = sl * C; i < i_e && affine; i++)
+		{
+			int o = row_of_sorted[i];
+			affine = (rp[o + 1] - rp[o]) == maxlen;
+		}
 		for (long k = 0; k < width; k++)
 		{
 			int lo = 0x7fffffff, hi = -1;
@@ -351,21 +359,23 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 					int c = ci[rp[o] + k];
 					lo = std::min(lo, c);
 					hi = std::max(hi, c);
+					if (affine && c != ci[rp[row_of_sorted[sl * C]] + k] + (int) (i - sl * C))
+						affine = false;
 				}
 			}
 			if (hi >= 0)
 				maxdelta = std::max<long>(maxdelta, (long) hi - lo);
 		}
-		const int md = maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		const int md = affine ? 0 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
 		mode[sl] = (unsigned char) md;
 		val_ptr[sl + 1] = width * C;
-		idx_ptr[sl + 1] = (width / 4) * (md == 1 ? 272 : md == 2 ? 528 : 1024);
+		idx_ptr[sl + 1] = (width / 4) * (md == 0 ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024);
 	}
 	for (long sl = 0; sl < num_slices; sl++)
 	{
 		val_ptr[sl + 1] += val_ptr[sl];
 		idx_ptr[sl + 1] += idx_ptr[sl];
-		A->sell_mode_slices[mode[sl] == 1 ? 0 : mode[sl] == 2 ? 1 : 2]++;
+		A->sell_mode_slices[mode[sl] == 0 ? 3 : mode[sl] == 1 ? 0 : mode[sl] == 2 ? 1 : 2]++;
 	}
 	const int64_t nnz_ext = val_ptr[num_slices];
 	const int64_t idx_bytes = idx_ptr[num_slices];
@@ -394,7 +404,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 			if (base == 0x7fffffff)
 				base = 0;                              // a step that is padding for every lane
 			const long g = k / 4, u = k % 4;
-			const long gbytes = md == 1 ? 272 : md == 2 ? 528 : 1024;
+			const long gbytes = md == 0 ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
 			unsigned char * gp = ib + g * gbytes;
 			if (md != 4)
 				reinterpret_cast<int *>(gp)[u] = base;
@@ -414,6 +424,8 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 				}
 				val[vb + k * C + r] = v;
 				const unsigned d = (unsigned) (c - base);
+				if (md == 0)
+					continue;                                  // affine: column = base + lane, nothing stored per lane
 				if (md == 1)
 					gp[16 + r * 4 + u] = (unsigned char) d;
 				else if (md == 2)
@@ -1296,7 +1308,7 @@ spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma
 				const long width = (h_desc[2 * sl + 2] - vb) / 64;
 				const int md = (int) (h_desc[2 * sl + 1] & 7);
 				const unsigned char * ib = h_idx.data() + (h_desc[2 * sl + 1] & ~(int64_t) 15);
-				const long gbytes = md == 1 ? 272 : md == 2 ? 528 : 1024;
+				const long gbytes = md == 0 ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
 				for (long k = 0; k < width; k++)
 				{
 					const unsigned char * gp = ib + (k / 4) * gbytes;
@@ -1304,7 +1316,9 @@ spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma
 					for (int r = 0; r < 64; r++)
 					{
 						int c;
-						if (md == 1)
+						if (md == 0)
+							c = reinterpret_cast<const int *>(gp)[u] + r;
+						else if (md == 1)
 							c = reinterpret_cast<const int *>(gp)[u] + gp[16 + r * 4 + u];
 						else if (md == 2)
 							c = reinterpret_cast<const int *>(gp)[u] + reinterpret_cast<const unsigned short *>(gp + 16)[r * 4 + u];
