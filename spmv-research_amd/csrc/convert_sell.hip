@@ -60,7 +60,7 @@ wave_max_i(int v)
 __device__ __forceinline__ long
 group_bytes(int md)
 {
-	return md == 0 ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
+	return (md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
 }
 
 // pass 1: one wave per slice -> mode, number of value slots, number of index bytes
@@ -83,8 +83,12 @@ slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, con
 	const int maxlen = wave_max_i(len);
 	const int width = (maxlen + 3) / 4 * 4;
 	int maxdelta = 0;
-	// affine (mode 0): a full slice of equally long rows whose step-k columns are base_k + lane
-	int affine = ((sl + 1) * WAVE <= m && n >= WAVE && wave_min_i(len) == maxlen) ? 1 : 0;
+	// step-invariant lane offsets (modes 0 and 3): a full slice of equally long rows whose step-k columns are
+	// c_k[lane 0] + off[lane] with the same off at every step; off = lane is the affine case (mode 0)
+	const bool uniform = (sl + 1) * WAVE <= m && n >= WAVE && wave_min_i(len) == maxlen;
+	int rowoff = (uniform && maxlen > 0) ? 1 : 0;
+	int affine = (uniform && maxlen == 0) ? 1 : 0;
+	int off = 0;
 	for (int k = 0; k < width; k++)
 	{
 		const bool ok = k < len;
@@ -93,15 +97,26 @@ slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, con
 		const int hi = wave_max_i(ok ? c : -1);
 		if (hi >= 0)
 			maxdelta = max(maxdelta, hi - lo);
-		if (affine && k < maxlen)
-			affine = wave_min_i((ok && c == __shfl(c, 0, WAVE) + lane) ? 1 : 0);
+		if (rowoff && k < maxlen)
+		{
+			const int rel = c - __shfl(c, 0, WAVE);
+			if (k == 0)
+			{
+				off = rel;
+				affine = wave_min_i(rel == lane ? 1 : 0);
+			}
+			else
+				rowoff = wave_min_i(rel == off ? 1 : 0);
+		}
 	}
+	if (!rowoff)
+		affine = (uniform && maxlen == 0) ? 1 : 0;
 	if (lane == 0)
 	{
-		const int md = affine ? 0 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		const int md = affine ? 0 : rowoff ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
 		mode[sl] = (unsigned char) md;
 		val_count[sl] = (int64_t) width * WAVE;
-		idx_count[sl] = (int64_t) (width / 4) * group_bytes(md);
+		idx_count[sl] = (int64_t) (md == 3 ? 4 * WAVE : 0) + (int64_t) (width / 4) * group_bytes(md);
 	}
 }
 
@@ -144,6 +159,16 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 		len = rp[o + 1] - start;
 	}
 	const long gbytes = group_bytes(md);
+	int pad_base = 0;
+	if (md == 3)
+	{
+		// header: the 64 lane offsets relative to lane 0's column, then the groups of 4 bases
+		const int c_first = ci[start];                     // every row of a mode-3 slice has at least one entry
+		const int off = c_first - __shfl(c_first, 0, WAVE);
+		reinterpret_cast<int *>(ib)[lane] = off;
+		pad_base = -wave_min_i(off);                       // all-padding steps: base + off must stay a valid column
+		ib += 4 * WAVE;
+	}
 	for (int g = 0; g < width / 4; g++)
 	{
 		unsigned char * gp = ib + g * gbytes;
@@ -157,6 +182,8 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 			int base = wave_min_i(c);
 			if (base == 0x7fffffff)
 				base = 0;                              // a step that is padding for every lane
+			if (md == 3)                               // base + off[lane]: lane 0's column on a real step
+				base = ok ? __shfl(c, 0, WAVE) : pad_base;
 			if (!ok)
 				c = base;                              // padding: value 0 times a column some lane really uses
 			val[vb + (long) k * WAVE + lane] = ok ? (T) va[start + k] : (T) 0;

@@ -143,18 +143,20 @@ typedef unsigned sell_uint2 __attribute__((ext_vector_type(2)));
 
 template <typename T, int MODE, bool NT>
 __device__ __forceinline__ void
-sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * __restrict__ vp, int lane, const T * __restrict__ x, T & s)
+sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * __restrict__ vp, int lane, const T * __restrict__ x, T & s,
+		int off = 0)
 {
 	int c0, c1, c2, c3;
-	if constexpr (MODE == 0)
+	if constexpr (MODE == 0 || MODE == 3)
 	{
-		// affine slice: the 64 rows are consecutive AND step k of lane l is column base_k + l (a stencil diagonal): no per-lane
-		// index bytes at all, one scalar base per step
+		// step-invariant lane offsets: column of lane l at step k = base_k + off_l. MODE 0 (affine slice: 64 consecutive rows of
+		// a stencil diagonal) has off_l = l; MODE 3 stores the 64 offsets once per slice (rows of one kind that are not
+		// consecutive). Either way no per-step index bytes per lane, one scalar base per step.
 		const sell_int4 base = *reinterpret_cast<const sell_int4 *>(gp);
-		c0 = base.x + lane;
-		c1 = base.y + lane;
-		c2 = base.z + lane;
-		c3 = base.w + lane;
+		c0 = base.x + off;
+		c1 = base.y + off;
+		c2 = base.z + off;
+		c3 = base.w + off;
 	}
 	else if constexpr (MODE == 1)
 	{
@@ -199,20 +201,26 @@ __device__ __forceinline__ T
 sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int groups, int lane, const T * __restrict__ x,
 		int g0 = 0, int gs = 1)
 {
-	constexpr int GB = MODE == 0 ? 16 : MODE == 1 ? 272 : MODE == 2 ? 528 : 1024;     // bytes of one index group
+	constexpr int GB = (MODE == 0 || MODE == 3) ? 16 : MODE == 1 ? 272 : MODE == 2 ? 528 : 1024;     // bytes of one index group
+	int off = lane;
+	if constexpr (MODE == 3)
+	{
+		off = ld_stream<NT>(reinterpret_cast<const int *>(ip) + lane);          // the slice's 64 lane offsets, then the groups
+		ip += 4 * WAVE;
+	}
 	T s = 0;
 	int g = g0;
 	for (; g + gs < groups; g += 2 * gs)    // 8 steps in flight per trip
 	{
-		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s);
-		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + gs) * GB, vp + (size_t) (g + gs) * 4 * WAVE, lane, x, s);
+		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
+		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + gs) * GB, vp + (size_t) (g + gs) * 4 * WAVE, lane, x, s, off);
 	}
 	if (g < groups)
-		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s);
+		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
 	return s;
 }
 
-// desc[2*s] = first value element of slice s, desc[2*s+1] = byte offset of its index block | mode (0, 1, 2 or 4) in the low bits
+// desc[2*s] = first value element of slice s, desc[2*s+1] = byte offset of its index block | mode (0, 1, 2, 3 or 4) in the low bits
 template <typename T, bool NT>
 __global__ __launch_bounds__(SELL_BLOCK) void
 sell_delta_kernel(const int64_t * __restrict__ desc, const unsigned char * __restrict__ idx, const T * __restrict__ val,
@@ -240,6 +248,8 @@ sell_delta_kernel(const int64_t * __restrict__ desc, const unsigned char * __res
 		s = sell_delta_slice<T, 1, NT>(ip, vp, groups, lane, x);
 	else if (mode == 2)
 		s = sell_delta_slice<T, 2, NT>(ip, vp, groups, lane, x);
+	else if (mode == 3)
+		s = sell_delta_slice<T, 3, NT>(ip, vp, groups, lane, x);
 	else
 		s = sell_delta_slice<T, 4, NT>(ip, vp, groups, lane, x);
 	const long sorted_row = (long) slice * WAVE + lane;
@@ -284,6 +294,8 @@ sell_delta_split_kernel(const int64_t * __restrict__ desc, const unsigned char *
 			s = sell_delta_slice<T, 1, NT>(ip, vp, groups, lane, x, w, S);
 		else if (mode == 2)
 			s = sell_delta_slice<T, 2, NT>(ip, vp, groups, lane, x, w, S);
+		else if (mode == 3)
+			s = sell_delta_slice<T, 3, NT>(ip, vp, groups, lane, x, w, S);
 		else
 			s = sell_delta_slice<T, 4, NT>(ip, vp, groups, lane, x, w, S);
 	}

@@ -341,12 +341,30 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 		const long maxlen = width;
 		width = (width + 3) / 4 * 4;
 		long maxdelta = 0;
-		// affine: a full slice of equally long rows whose step-k columns are base_k + lane (consecutive rows of a stencil)
-		bool affine = (sl + 1) * C <= m && A->n >= C;
-		for (long i = sl * C; i < i_e && affine; i++)
+		// step-invariant lane offsets: a full slice of equally long rows whose step-k columns are c_k[lane 0] + off[lane] with the
+		// SAME off for every step (rows of one kind of a stencil: column = row + const_k). off = lane is the affine case.
+		bool rowoff = (sl + 1) * C <= m && A->n >= C && maxlen > 0;
+		for (long i = sl * C; i < i_e && rowoff; i++)
 		{
 			int o = row_of_sorted[i];
-			affine = (rp[o + 1] - rp[o]) == maxlen;
+			rowoff = (rp[o + 1] - rp[o]) == maxlen;
+		}
+		bool affine = (sl + 1) * C <= m && A->n >= C && maxlen == 0;      // an all-empty slice stores nothing either
+		if (rowoff)
+		{
+			const int o0 = row_of_sorted[sl * C];
+			affine = true;
+			for (long i = sl * C; i < i_e && rowoff; i++)
+			{
+				const int o = row_of_sorted[i];
+				const int off = ci[rp[o]] - ci[rp[o0]];
+				if (off != (int) (i - sl * C))
+					affine = false;
+				for (long k = 1; k < maxlen && rowoff; k++)
+					rowoff = ci[rp[o] + k] - ci[rp[o0] + k] == off;
+			}
+			if (!rowoff)
+				affine = false;
 		}
 		for (long k = 0; k < width; k++)
 		{
@@ -359,23 +377,21 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 					int c = ci[rp[o] + k];
 					lo = std::min(lo, c);
 					hi = std::max(hi, c);
-					if (affine && c != ci[rp[row_of_sorted[sl * C]] + k] + (int) (i - sl * C))
-						affine = false;
 				}
 			}
 			if (hi >= 0)
 				maxdelta = std::max<long>(maxdelta, (long) hi - lo);
 		}
-		const int md = affine ? 0 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		const int md = affine ? 0 : rowoff ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
 		mode[sl] = (unsigned char) md;
 		val_ptr[sl + 1] = width * C;
-		idx_ptr[sl + 1] = (width / 4) * (md == 0 ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024);
+		idx_ptr[sl + 1] = (md == 3 ? 4 * C : 0) + (width / 4) * ((md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024);
 	}
 	for (long sl = 0; sl < num_slices; sl++)
 	{
 		val_ptr[sl + 1] += val_ptr[sl];
 		idx_ptr[sl + 1] += idx_ptr[sl];
-		A->sell_mode_slices[mode[sl] == 0 ? 3 : mode[sl] == 1 ? 0 : mode[sl] == 2 ? 1 : 2]++;
+		A->sell_mode_slices[(mode[sl] == 0 || mode[sl] == 3) ? 3 : mode[sl] == 1 ? 0 : mode[sl] == 2 ? 1 : 2]++;
 	}
 	const int64_t nnz_ext = val_ptr[num_slices];
 	const int64_t idx_bytes = idx_ptr[num_slices];
@@ -392,6 +408,19 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 		desc[2 * sl] = vb;
 		desc[2 * sl + 1] = idx_ptr[sl] | md;
 		const long i_e = std::min(m, (sl + 1) * C);
+		int min_off = 0;
+		if (md == 3)
+		{
+			// header: the 64 lane offsets (relative to lane 0's column), then the groups of 4 bases
+			const int o0 = row_of_sorted[sl * C];
+			for (int r = 0; r < C; r++)
+			{
+				const int off = ci[rp[row_of_sorted[sl * C + r]]] - ci[rp[o0]];
+				reinterpret_cast<int *>(ib)[r] = off;
+				min_off = std::min(min_off, off);
+			}
+			ib += 4 * C;
+		}
 		for (long k = 0; k < width; k++)
 		{
 			int base = 0x7fffffff;
@@ -403,8 +432,10 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 			}
 			if (base == 0x7fffffff)
 				base = 0;                              // a step that is padding for every lane
+			if (md == 3)                               // base + off[lane] must be lane 0's column (real step) / a valid column (padding)
+				base = (k < rp[row_of_sorted[sl * C] + 1] - rp[row_of_sorted[sl * C]]) ? ci[rp[row_of_sorted[sl * C]] + k] : -min_off;
 			const long g = k / 4, u = k % 4;
-			const long gbytes = md == 0 ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
+			const long gbytes = (md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
 			unsigned char * gp = ib + g * gbytes;
 			if (md != 4)
 				reinterpret_cast<int *>(gp)[u] = base;
@@ -424,8 +455,8 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 				}
 				val[vb + k * C + r] = v;
 				const unsigned d = (unsigned) (c - base);
-				if (md == 0)
-					continue;                                  // affine: column = base + lane, nothing stored per lane
+				if (md == 0 || md == 3)
+					continue;                                  // column = base + lane offset, nothing stored per lane and step
 				if (md == 1)
 					gp[16 + r * 4 + u] = (unsigned char) d;
 				else if (md == 2)
@@ -1308,7 +1339,10 @@ spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma
 				const long width = (h_desc[2 * sl + 2] - vb) / 64;
 				const int md = (int) (h_desc[2 * sl + 1] & 7);
 				const unsigned char * ib = h_idx.data() + (h_desc[2 * sl + 1] & ~(int64_t) 15);
-				const long gbytes = md == 0 ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
+				const int * offs = reinterpret_cast<const int *>(ib);
+				if (md == 3)
+					ib += 4 * 64;
+				const long gbytes = (md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
 				for (long k = 0; k < width; k++)
 				{
 					const unsigned char * gp = ib + (k / 4) * gbytes;
@@ -1318,6 +1352,8 @@ spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma
 						int c;
 						if (md == 0)
 							c = reinterpret_cast<const int *>(gp)[u] + r;
+						else if (md == 3)
+							c = reinterpret_cast<const int *>(gp)[u] + offs[r];
 						else if (md == 1)
 							c = reinterpret_cast<const int *>(gp)[u] + gp[16 + r * 4 + u];
 						else if (md == 2)
