@@ -5,7 +5,7 @@
 // checker: this path must produce the SAME bytes (tests/test_gpu_parity.py compares the two layouts).
 //   1. row lengths; stable sort of the rows of every sigma-window by length, descending (radix_sort.c:103-122 semantics):
 //      one segmented radix sort (hipCUB; radix sort is stable, so equal lengths keep their row order);
-//   2. one wave per 64-row slice: width (max length, padded to 4 steps) and the narrowest index encoding that holds every
+//   2. one wave per 64-row slice: width (max length; index groups cover it rounded up to 4 steps) and the narrowest index encoding that holds every
 //      (step, lane) delta against the step's minimum column;
 //   3. exclusive scans -> value / index offsets of the slices;
 //   4. one wave per slice fills values (column-major, narrowed to the handle's precision), step bases and packed deltas.
@@ -115,7 +115,7 @@ slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, con
 	{
 		const int md = affine ? 0 : rowoff ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
 		mode[sl] = (unsigned char) md;
-		val_count[sl] = (int64_t) width * WAVE;
+		val_count[sl] = (int64_t) maxlen * WAVE;             // values: exact width; index groups: rounded up to 4 steps
 		idx_count[sl] = (int64_t) (md == 3 ? 4 * WAVE : 0) + (int64_t) (width / 4) * group_bytes(md);
 	}
 }
@@ -142,7 +142,8 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 		return;
 	}
 	const int64_t vb = val_ptr[sl];
-	const int width = (int) ((val_ptr[sl + 1] - vb) / WAVE);
+	const int maxlen = (int) ((val_ptr[sl + 1] - vb) / WAVE);
+	const int width = (maxlen + 3) / 4 * 4;
 	const int md = mode[sl];
 	unsigned char * ib = idx + idx_ptr[sl];
 	if (lane == 0)
@@ -186,7 +187,8 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 				base = ok ? __shfl(c, 0, WAVE) : pad_base;
 			if (!ok)
 				c = base;                              // padding: value 0 times a column some lane really uses
-			val[vb + (long) k * WAVE + lane] = ok ? (T) va[start + k] : (T) 0;
+			if (k < maxlen)                            // steps past the slice's longest row exist in the index groups only
+				val[vb + (long) k * WAVE + lane] = ok ? (T) va[start + k] : (T) 0;
 			if (md != 4)
 			{
 				if (lane == 0)

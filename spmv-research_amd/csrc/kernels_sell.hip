@@ -141,7 +141,7 @@ sell_kernel(const int64_t * __restrict__ slice_ptr, const int * __restrict__ col
 typedef int sell_int4 __attribute__((ext_vector_type(4)));
 typedef unsigned sell_uint2 __attribute__((ext_vector_type(2)));
 
-template <typename T, int MODE, bool NT>
+template <typename T, int MODE, bool NT, int NSTEPS = 4>
 __device__ __forceinline__ void
 sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * __restrict__ vp, int lane, const T * __restrict__ x, T & s,
 		int off = 0)
@@ -184,24 +184,42 @@ sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * 
 		c2 = ld_stream<NT>(cp + 2 * WAVE);
 		c3 = ld_stream<NT>(cp + 3 * WAVE);
 	}
-	const T v0 = ld_stream<NT>(vp);
-	const T v1 = ld_stream<NT>(vp + WAVE);
-	const T v2 = ld_stream<NT>(vp + 2 * WAVE);
-	const T v3 = ld_stream<NT>(vp + 3 * WAVE);
-	const T x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-	s = fma_t<T>(v0, x0, s);
-	s = fma_t<T>(v1, x1, s);
-	s = fma_t<T>(v2, x2, s);
-	s = fma_t<T>(v3, x3, s);
+	if (NSTEPS == 4)
+	{
+		const T v0 = ld_stream<NT>(vp);
+		const T v1 = ld_stream<NT>(vp + WAVE);
+		const T v2 = ld_stream<NT>(vp + 2 * WAVE);
+		const T v3 = ld_stream<NT>(vp + 3 * WAVE);
+		const T x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+		s = fma_t<T>(v0, x0, s);
+		s = fma_t<T>(v1, x1, s);
+		s = fma_t<T>(v2, x2, s);
+		s = fma_t<T>(v3, x3, s);
+	}
+	else
+	{
+		// last group of a slice whose width is not a multiple of 4: the value array holds only the real steps
+		const T v0 = ld_stream<NT>(vp);
+		const T v1 = NSTEPS > 1 ? ld_stream<NT>(vp + WAVE) : T(0);
+		const T v2 = NSTEPS > 2 ? ld_stream<NT>(vp + 2 * WAVE) : T(0);
+		const T x0 = x[c0];
+		const T x1 = NSTEPS > 1 ? x[c1] : T(0);
+		const T x2 = NSTEPS > 2 ? x[c2] : T(0);
+		s = fma_t<T>(v0, x0, s);
+		if (NSTEPS > 1) s = fma_t<T>(v1, x1, s);
+		if (NSTEPS > 2) s = fma_t<T>(v2, x2, s);
+	}
 }
 
 // groups g0, g0+gs, g0+2gs, ... of one slice (gs = 1: the whole slice, in order)
 template <typename T, int MODE, bool NT>
 __device__ __forceinline__ T
-sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int groups, int lane, const T * __restrict__ x,
+sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int width, int lane, const T * __restrict__ x,
 		int g0 = 0, int gs = 1)
 {
 	constexpr int GB = (MODE == 0 || MODE == 3) ? 16 : MODE == 1 ? 272 : MODE == 2 ? 528 : 1024;     // bytes of one index group
+	const int groups = (width + 3) / 4;     // index groups cover the width rounded up to 4 steps, values only the real steps
+	const int rem = width - 4 * (groups - 1);
 	int off = lane;
 	if constexpr (MODE == 3)
 	{
@@ -210,13 +228,23 @@ sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ v
 	}
 	T s = 0;
 	int g = g0;
-	for (; g + gs < groups; g += 2 * gs)    // 8 steps in flight per trip
+	const int last = groups - 1;            // the last group holds `rem` (1..4) steps
+	for (; g + gs < (rem == 4 ? groups : last); g += 2 * gs)    // 8 steps in flight per trip
 	{
 		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
 		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + gs) * GB, vp + (size_t) (g + gs) * 4 * WAVE, lane, x, s, off);
 	}
-	if (g < groups)
+	for (; g < (rem == 4 ? groups : last); g += gs)
 		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
+	if (rem != 4 && g == last)
+	{
+		if (rem == 1)
+			sell_delta_group<T, MODE, NT, 1>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
+		else if (rem == 2)
+			sell_delta_group<T, MODE, NT, 2>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
+		else
+			sell_delta_group<T, MODE, NT, 3>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
+	}
 	return s;
 }
 
@@ -240,7 +268,7 @@ sell_delta_kernel(const int64_t * __restrict__ desc, const unsigned char * __res
 	const int mode = (int) (i_word & 7);
 	const unsigned char * ip = idx + (i_word & ~(int64_t) 15);
 	const T * vp = val + v_off + lane;
-	const int groups = (int) ((v_next - v_off) / (4 * WAVE));
+	const int groups = (int) ((v_next - v_off) / WAVE);       // = the slice's width in steps (name kept: passed as `width`)
 	T s;
 	if (mode == 0)
 		s = sell_delta_slice<T, 0, NT>(ip, vp, groups, lane, x);
@@ -287,7 +315,7 @@ sell_delta_split_kernel(const int64_t * __restrict__ desc, const unsigned char *
 		const int mode = (int) (i_word & 7);
 		const unsigned char * ip = idx + (i_word & ~(int64_t) 15);
 		const T * vp = val + v_off + lane;
-		const int groups = (int) ((v_next - v_off) / (4 * WAVE));
+		const int groups = (int) ((v_next - v_off) / WAVE);       // = the slice's width in steps (name kept: passed as `width`)
 		if (mode == 0)
 			s = sell_delta_slice<T, 0, NT>(ip, vp, groups, lane, x, w, S);
 		else if (mode == 1)

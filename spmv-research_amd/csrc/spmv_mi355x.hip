@@ -384,7 +384,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 		}
 		const int md = affine ? 0 : rowoff ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
 		mode[sl] = (unsigned char) md;
-		val_ptr[sl + 1] = width * C;
+		val_ptr[sl + 1] = maxlen * C;                    // values: exact width; index groups: rounded up to 4 steps
 		idx_ptr[sl + 1] = (md == 3 ? 4 * C : 0) + (width / 4) * ((md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024);
 	}
 	for (long sl = 0; sl < num_slices; sl++)
@@ -402,7 +402,8 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 	for (long sl = 0; sl < num_slices; sl++)
 	{
 		const int64_t vb = val_ptr[sl];
-		const long width = (val_ptr[sl + 1] - vb) / C;
+		const long maxlen = (val_ptr[sl + 1] - vb) / C;
+		const long width = (maxlen + 3) / 4 * 4;
 		const int md = mode[sl];
 		unsigned char * ib = idx.data() + idx_ptr[sl];
 		desc[2 * sl] = vb;
@@ -453,7 +454,8 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 						v = va[rp[o] + k];
 					}
 				}
-				val[vb + k * C + r] = v;
+				if (k < maxlen)
+					val[vb + k * C + r] = v;                   // steps past the longest row exist in the index groups only
 				const unsigned d = (unsigned) (c - base);
 				if (md == 0 || md == 3)
 					continue;                                  // column = base + lane offset, nothing stored per lane and step
