@@ -65,7 +65,7 @@ template <typename T, int IPT, bool NT>
 __global__ __launch_bounds__(MERGE_BLOCK) void
 merge_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
 		const T * __restrict__ x, T * __restrict__ y, int m, const int * __restrict__ coords,
-		int * __restrict__ carry_row, T * __restrict__ carry_val, int beta, XcdMap map)
+		int * __restrict__ carry_row, T * __restrict__ carry_val, int beta, T unit, XcdMap map)
 {
 	constexpr int TILE = MERGE_BLOCK * IPT;
 	// rows_in_tile + nnz_in_tile <= TILE: products first, row ends behind them, in one buffer
@@ -99,7 +99,7 @@ merge_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, con
 			bool ok = idx < tile_nnz;
 			long j = (long) nz0 + (ok ? idx : 0);
 			c[k] = ok ? ld_stream<NT>(col + j) : 0;
-			v[k] = ok ? ld_stream<NT>(val + j) : T(0);
+			v[k] = ok ? (val ? ld_stream<NT>(val + j) : unit) : T(0);      // val == nullptr: all stored values equal `unit` (pattern matrix)
 		}
 		for (int idx = tid; idx < tile_rows; idx += MERGE_BLOCK)
 			s_row_end[idx] = row_end[row0 + idx];
@@ -272,10 +272,10 @@ merge_launch_ipt(const int * row_ptr, const int * col, const void * val, const v
 		return 0;
 	if (cfg.nt)
 		hipLaunchKernelGGL((merge_kernel<T, IPT, true>), dim3(grid), dim3(MERGE_BLOCK), 0, stream, row_ptr, col, (const T *) val,
-				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, cfg.map);
+				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, (T) cfg.unit_value, cfg.map);
 	else
 		hipLaunchKernelGGL((merge_kernel<T, IPT, false>), dim3(grid), dim3(MERGE_BLOCK), 0, stream, row_ptr, col, (const T *) val,
-				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, cfg.map);
+				(const T *) x, (T *) y, m, coords, carry_row, (T *) carry_val, cfg.beta, (T) cfg.unit_value, cfg.map);
 	HIP_TRY(hipGetLastError());
 	unsigned fgrid = (ntiles + MERGE_BLOCK - 1) / MERGE_BLOCK;
 	hipLaunchKernelGGL((merge_fixup_kernel<T>), dim3(fgrid), dim3(MERGE_BLOCK), 0, stream, carry_row, (const T *) carry_val,

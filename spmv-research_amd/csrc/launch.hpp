@@ -12,6 +12,8 @@ struct LaunchCfg {
 	XcdMap map;         // tile order over the 8 XCDs (built at conversion time for the kernel's tile geometry)
 	int nt;             // nontemporal matrix streams
 	int beta;           // 0: y = A x, 1: y += A x
+	int unit;           // merge path: every stored value equals unit_value (pattern matrices: 1.0) and the value array is not kept
+	double unit_value;
 };
 
 // tile geometry of each kernel family (units per workgroup), needed to build the XCD map

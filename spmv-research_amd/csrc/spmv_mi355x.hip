@@ -1027,6 +1027,28 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 				}
 				A->cfg.map = xcd_map_uniform((unsigned) A->merge_num_tiles, resolve_remap(A->remap, 0));      // tiles hold equal work by construction
 				A->mem_footprint += 2.0 * (A->merge_num_tiles + 1) * 4;
+				// Pattern matrices (Matrix-Market `pattern`: every value is the dummy 1.0, matrix_market.c:308-317 — the
+				// soc-LiveJournal1 configuration) carry no information in the value array: keep the constant, drop the stream.
+				bool uniform = lnnz > 0;
+				{
+					long differs = 0;
+					const double v0 = lnnz > 0 ? (A->f32 ? (double) (float) va[0] : va[0]) : 0.0;
+					#pragma omp parallel for num_threads(spmv::host_threads()) reduction(+ : differs)
+					for (long j = 0; j < lnnz; j++)
+						differs += (A->f32 ? (double) (float) va[j] : va[j]) != v0;
+					uniform = uniform && differs == 0 && v0 == v0;
+					if (uniform)
+					{
+						(void) hipFree(A->d_val);
+						A->d_val = nullptr;
+						A->cfg.unit = 1;
+						A->cfg.unit_value = v0;
+						A->mem_footprint -= (double) lnnz * A->vbytes;
+					}
+				}
+				if (uniform)
+					snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_MERGE_i%d_unit_%s", A->merge_ipt, pf);
+				else
 				snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_MERGE_i%d_%s", A->merge_ipt, pf);
 				snprintf(A->kernel_name, sizeof(A->kernel_name), "merge_kernel");
 			}

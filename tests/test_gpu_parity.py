@@ -434,3 +434,31 @@ def test_gpu_kernels_against_the_reference_build_on_random_matrices(eng):
                 A = eng.Matrix(rp, ci, a, m, n, fmt, dtype, **opts)
                 check(A.spmv(x), y_ref, absrow, dtype, exact, f"vs reference build: trial {trial} {kind} {fmt} {np.dtype(dtype).name}")
                 A.close()
+
+
+def test_merge_drops_the_value_stream_of_pattern_matrices(eng, oracle):
+    """Matrix-Market `pattern` matrices (soc-LiveJournal1) hold the dummy value 1.0 everywhere (matrix_market.c:308-317): the
+    merge kernel keeps the constant and not the array — same bits as with the array, smaller footprint."""
+    rng = np.random.default_rng(5)
+    rp, ci, a = synth(rng, 30000, 30000, "powerlaw")
+    x = rng.uniform(-1, 1, 30000)
+    for const in (1.0, -2.5):
+        ones = np.full(len(ci), const)
+        for dtype in (np.float64, np.float32):
+            U = eng.Matrix(rp, ci, ones, 30000, 30000, "csr_merge", dtype)
+            assert "_unit_" in U.format_name and U.mem_footprint < U.csr_mem_footprint
+            # the same matrix with ONE different value keeps its array: identical arithmetic elsewhere
+            pert = ones.copy()
+            pert[-1] = const * 2
+            G = eng.Matrix(rp, ci, pert, 30000, 30000, "csr_merge", dtype)
+            assert "_unit_" not in G.format_name
+            yu, yg = U.spmv(x), G.spmv(x)
+            last_row = int(np.searchsorted(rp, len(ci) - 1, side="right") - 1)
+            keep = np.ones(30000, bool)
+            keep[last_row] = False
+            np.testing.assert_array_equal(yu[keep], yg[keep])
+            y_ref = oracle.csr_spmv(rp, ci, ones, x, dtype, num_threads=2)
+            absrow = oracle.csr_spmv(rp, ci, np.abs(ones), np.abs(x))
+            check(yu, y_ref, absrow, dtype, False, f"unit merge {const} {np.dtype(dtype).name}")
+            U.close()
+            G.close()
