@@ -7,7 +7,7 @@
 // statistics_print_labels). The kernel family is chosen at compile time with -DSPMV_MI355X_FORMAT=<id> (one executable
 // per format, like every other backend) or at run time with the environment variable SPMV_MI355X_FORMAT
 // (csr_scalar | csr_vector | csr_merge | sell_c_sigma | coo | csr_stream); tunables via SPMV_MI355X_LANES_PER_ROW, _SELL_C,
-// _SELL_SIGMA, _MERGE_ITEMS. Errors end the process the way the reference's error() does (lib/debug.h:83-135).
+// _SELL_SIGMA, _SELL_DELTA, _SELL_SPLIT, _MERGE_ITEMS, _STREAM_MODE, _ROWS_PER_GROUP, _XCD_REMAP (the fields of spmv_mi355x_opts). Errors end the process the way the reference's error() does (lib/debug.h:83-135).
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -65,6 +65,11 @@ struct MI355XFormat : Matrix_Format
 		o.sell_c = env_int("SPMV_MI355X_SELL_C", 0);
 		o.sell_sigma = env_int("SPMV_MI355X_SELL_SIGMA", 0);
 		o.merge_items = env_int("SPMV_MI355X_MERGE_ITEMS", 0);
+		o.stream_mode = env_int("SPMV_MI355X_STREAM_MODE", 0);
+		o.rows_per_group = env_int("SPMV_MI355X_ROWS_PER_GROUP", 0);
+		o.sell_delta = env_int("SPMV_MI355X_SELL_DELTA", 0);
+		o.sell_split = env_int("SPMV_MI355X_SELL_SPLIT", 0);
+		o.xcd_remap = env_int("SPMV_MI355X_XCD_REMAP", 0);
 		o.symmetric_input = symmetric_input;
 		const int precision = (sizeof(ValueType) == 8) ? SPMV_MI355X_F64 : SPMV_MI355X_F32;
 		// deep copy happens inside create(): the driver frees its CSR right after this call (bench.cpp:605-629)
