@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spmv-research_amd", "python"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
-DEFAULT_FORMAT = {"nlpkkt240": "sell_c_sigma", "cant": "csr_vector", "pwtk": "csr_stream",
+DEFAULT_FORMAT = {"nlpkkt240": "sell_c_sigma", "cant": "csr_stream", "pwtk": "csr_stream",
                   "scircuit": "csr_vector", "soc-LiveJournal1": "csr_merge"}
 DEFAULT_DTYPE = {"pwtk": "f32"}
 

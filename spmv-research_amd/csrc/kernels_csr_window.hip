@@ -23,9 +23,9 @@ namespace spmv {
 
 constexpr int WIN_BLOCK = 1024;
 
-template <typename T, int G, bool NT, bool LDSX>
+template <typename T, typename CI, int G, bool NT, bool LDSX>
 __device__ __forceinline__ void
-window_rows(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
+window_rows(const int * __restrict__ row_ptr, const CI * __restrict__ col, const T * __restrict__ val,
 		const T * __restrict__ x, const T * __restrict__ xs, T * __restrict__ y, int r0, int r1, int lo, int beta)
 {
 	constexpr int U = 4;
@@ -52,7 +52,7 @@ window_rows(const int * __restrict__ row_ptr, const int * __restrict__ col, cons
 	{
 		const int j = js0 + lane + u * G;
 		const bool ok = j < je0;
-		c[u] = ok ? ld_stream<NT>(col + j) : -1;
+		c[u] = ok ? (int) ld_stream<NT>(col + j) : -1;
 		v[u] = ok ? ld_stream<NT>(val + j) : (T) 0;
 	}
 	while (row < r1)
@@ -72,7 +72,7 @@ window_rows(const int * __restrict__ row_ptr, const int * __restrict__ col, cons
 		{
 			const int j = js1 + lane + u * G;
 			const bool ok = j < je1;
-			cn0[u] = ok ? ld_stream<NT>(col + j) : -1;
+			cn0[u] = ok ? (int) ld_stream<NT>(col + j) : -1;
 			vn0[u] = ok ? ld_stream<NT>(val + j) : (T) 0;
 		}
 		T acc[U];
@@ -102,7 +102,7 @@ window_rows(const int * __restrict__ row_ptr, const int * __restrict__ col, cons
 				{
 					const int j = jb + lane + u * G;
 					const bool ok = j < je0;
-					cn[u] = ok ? ld_stream<NT>(col + j) : -1;
+					cn[u] = ok ? (int) ld_stream<NT>(col + j) : -1;
 					vn[u] = ok ? ld_stream<NT>(val + j) : (T) 0;
 				}
 			}
@@ -141,9 +141,9 @@ window_rows(const int * __restrict__ row_ptr, const int * __restrict__ col, cons
 // RPG consecutive rows of a lane group in flight together (as csr_vector_multi_kernel), x from the LDS window. The row
 // pointers of the group's NEXT set of rows are loaded before the current set is consumed, so a set costs one exposed
 // global round trip (its index/value batches); the two-deep single-row pipeline of window_rows() exposes one per row.
-template <typename T, int G, int RPG, bool NT, bool LDSX>
+template <typename T, typename CI, int G, int RPG, bool NT, bool LDSX>
 __device__ __forceinline__ void
-window_rows_multi(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
+window_rows_multi(const int * __restrict__ row_ptr, const CI * __restrict__ col, const T * __restrict__ val,
 		const T * __restrict__ x, const T * __restrict__ xs, T * __restrict__ y, int r0, int r1, int lo, int beta)
 {
 	constexpr int U = 4;
@@ -178,7 +178,7 @@ window_rows_multi(const int * __restrict__ row_ptr, const int * __restrict__ col
 				for (int u = 0; u < U; u++)
 				{
 					const bool ok = j[r] + u * G < je[r];
-					c[r][u] = ok ? ld_stream<NT>(col + j[r] + u * G) : -1;
+					c[r][u] = ok ? (int) ld_stream<NT>(col + j[r] + u * G) : -1;
 					v[r][u] = ok ? ld_stream<NT>(val + j[r] + u * G) : (T) 0;
 				}
 			any = false;
@@ -213,9 +213,11 @@ window_rows_multi(const int * __restrict__ row_ptr, const int * __restrict__ col
 	}
 }
 
-template <typename T, int G, bool NT>
+// CI = int: global column indices. CI = unsigned short: indices RELATIVE to the block's window (every block has one and
+// no window is wider than 65 536 columns) — 2 bytes per non-zero instead of 4 in the stream, and no subtraction.
+template <typename T, typename CI, int G, bool NT>
 __global__ __launch_bounds__(WIN_BLOCK) void
-csr_window_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
+csr_window_kernel(const int * __restrict__ row_ptr, const CI * __restrict__ col, const T * __restrict__ val,
 		const T * __restrict__ x, T * __restrict__ y, int beta, const int * __restrict__ blk_row,
 		const int * __restrict__ blk_lo, const int * __restrict__ blk_w, int multi_rows, XcdMap map)
 {
@@ -225,35 +227,37 @@ csr_window_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col
 	if (tile == NO_TILE)
 		return;
 	const int r0 = blk_row[tile], r1 = blk_row[tile + 1];
-	const int lo = blk_lo[tile], w = blk_w[tile];
+	const int lo_x = blk_lo[tile], w = blk_w[tile];
+	const int lo = sizeof(CI) == 2 ? 0 : lo_x;          // what the stored indices are relative to
 	if (w > 0)
 	{
 		for (int i = threadIdx.x; i < w; i += WIN_BLOCK)
-			xs[i] = x[lo + i];
+			xs[i] = x[lo_x + i];
 		__syncthreads();
 		// measured: several rows in flight win while the window is small (cant twin fp32 8.3 -> 7.1 us; many workgroups per
 		// CU), the two-deep single-row pipeline wins with ~50 KiB windows (pwtk twin fp32 18.6 vs 19.6 us)
 		if constexpr (G <= 32)
 		{
 			if (multi_rows)
-				window_rows_multi<T, G, (G <= 16 ? 4 : 2), NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
+				window_rows_multi<T, CI, G, (G <= 16 ? 4 : 2), NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
 			else
-				window_rows<T, G, NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
+				window_rows<T, CI, G, NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
 		}
 		else
-			window_rows<T, G, NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
+			window_rows<T, CI, G, NT, true>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
 	}
 	else
-		window_rows<T, G, NT, false>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
+		window_rows<T, CI, G, NT, false>(row_ptr, col, val, x, xs, y, r0, r1, lo, beta);
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
 
-template <typename T, int G>
+template <typename T, typename CI, int G>
 static int
-csr_window_launch(const int * row_ptr, const int * col, const void * val, const void * x, void * y, const int * blk_row,
+csr_window_launch(const int * row_ptr, const void * col_v, const void * val, const void * x, void * y, const int * blk_row,
 		const int * blk_lo, const int * blk_w, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
+	const CI * col = (const CI *) col_v;
 	unsigned grid = xcd_grid(cfg.map);
 	if (grid_out)
 		*grid_out = grid;
@@ -265,34 +269,34 @@ csr_window_launch(const int * row_ptr, const int * col, const void * val, const 
 	if (lds_bytes > have)
 	{
 		if (cfg.nt)
-			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_window_kernel<T, G, true>),
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_window_kernel<T, CI, G, true>),
 					hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 		else
-			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_window_kernel<T, G, false>),
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_window_kernel<T, CI, G, false>),
 					hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 		have = lds_bytes;
 	}
 	if (cfg.nt)
-		hipLaunchKernelGGL((csr_window_kernel<T, G, true>), dim3(grid), dim3(WIN_BLOCK), lds_bytes, stream, row_ptr, col,
+		hipLaunchKernelGGL((csr_window_kernel<T, CI, G, true>), dim3(grid), dim3(WIN_BLOCK), lds_bytes, stream, row_ptr, col,
 				(const T *) val, (const T *) x, (T *) y, cfg.beta, blk_row, blk_lo, blk_w, lds_bytes <= 16384 ? 1 : 0, cfg.map);
 	else
-		hipLaunchKernelGGL((csr_window_kernel<T, G, false>), dim3(grid), dim3(WIN_BLOCK), lds_bytes, stream, row_ptr, col,
+		hipLaunchKernelGGL((csr_window_kernel<T, CI, G, false>), dim3(grid), dim3(WIN_BLOCK), lds_bytes, stream, row_ptr, col,
 				(const T *) val, (const T *) x, (T *) y, cfg.beta, blk_row, blk_lo, blk_w, lds_bytes <= 16384 ? 1 : 0, cfg.map);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
 
-template <typename T>
+template <typename T, typename CI>
 static int
-csr_window_dispatch(int G, const int * row_ptr, const int * col, const void * val, const void * x, void * y, const int * blk_row,
+csr_window_dispatch(int G, const int * row_ptr, const void * col, const void * val, const void * x, void * y, const int * blk_row,
 		const int * blk_lo, const int * blk_w, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
 	switch (G)
 	{
-		case 8:  return csr_window_launch<T, 8>(row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
-		case 16: return csr_window_launch<T, 16>(row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
-		case 32: return csr_window_launch<T, 32>(row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
-		case 64: return csr_window_launch<T, 64>(row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
+		case 8:  return csr_window_launch<T, CI, 8>(row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
+		case 16: return csr_window_launch<T, CI, 16>(row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
+		case 32: return csr_window_launch<T, CI, 32>(row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
+		case 64: return csr_window_launch<T, CI, 64>(row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
 	}
 	set_error("csr_stream mode 4: lanes_per_row must be 8, 16, 32 or 64 (got %d)", G);
 	return 1;
@@ -305,12 +309,15 @@ csr_window_lds_budget()
 }
 
 int
-launch_csr_window(bool f32, int lanes_per_row, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+launch_csr_window(bool f32, int lanes_per_row, const int * row_ptr, const void * col, int col16, const void * val, const void * x, void * y,
 		const int * blk_row, const int * blk_lo, const int * blk_w, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream,
 		long * grid_out)
 {
-	return f32 ? csr_window_dispatch<float>(lanes_per_row, row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out)
-	           : csr_window_dispatch<double>(lanes_per_row, row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
+	if (col16)
+		return f32 ? csr_window_dispatch<float, unsigned short>(lanes_per_row, row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out)
+		           : csr_window_dispatch<double, unsigned short>(lanes_per_row, row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
+	return f32 ? csr_window_dispatch<float, int>(lanes_per_row, row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out)
+	           : csr_window_dispatch<double, int>(lanes_per_row, row_ptr, col, val, x, y, blk_row, blk_lo, blk_w, lds_bytes, cfg, stream, grid_out);
 }
 
 }  // namespace spmv

@@ -46,7 +46,7 @@ constexpr int STREAM_SLACK = 512;                                      // entrie
 
 // CSR with the block's x window in LDS (kernels_csr_window.hip)
 int csr_window_lds_budget();                                           // bytes of LDS a block's window may take
-int launch_csr_window(bool f32, int lanes_per_row, const int * row_ptr, const int * col, const void * val, const void * x, void * y,
+int launch_csr_window(bool f32, int lanes_per_row, const int * row_ptr, const void * col, int col16, const void * val, const void * x, void * y,
 		const int * blk_row, const int * blk_lo, const int * blk_w, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream,
 		long * grid_out);
 

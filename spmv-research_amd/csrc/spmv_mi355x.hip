@@ -49,6 +49,7 @@ struct spmv_mi355x_matrix {
 	int * d_win_row = nullptr;             // CSR_STREAM mode 4: row block boundaries, window start, window length (0 = no LDS window)
 	int * d_win_lo = nullptr;
 	int * d_win_w = nullptr;
+	unsigned short * d_col16 = nullptr;    // mode 4 with every window <= 65 536 columns: indices relative to the block's window
 	int win_blocks = 0, win_lds_bytes = 0;
 	int stream_mode = 0;                   // CSR_STREAM: 1 = products in LDS (row-major gather), 2 = (val,col) in LDS, lane-per-row walk
 	// merge
@@ -112,7 +113,7 @@ free_all(spmv_mi355x_matrix * A)
 {
 	void * ptrs[] = {A->d_row_ptr, A->d_col, A->d_val, A->d_coords, A->d_carry_row, A->d_carry_val, A->d_slice_ptr,
 	                 A->d_row_of_sorted, A->d_rowind, A->d_x, A->d_y, A->d_sell_desc, A->d_sell_idx, A->d_win_row, A->d_win_lo,
-	                 A->d_win_w};
+	                 A->d_win_w, A->d_col16};
 	for (void * p : ptrs)
 		if (p)
 			(void) hipFree(p);
@@ -837,7 +838,8 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 				// x window in LDS (kernels_csr_window.hip): nnz-balanced row blocks, a multiple of the 256 CUs. Forced by
 				// stream_mode 4; in auto mode adopted when (nearly) every block's window fits the LDS budget and rows are long
 				// enough to amortise the per-row butterfly (measured: pwtk twin fp32 22.1 -> 18.6 us; short-row / scattered
-				// matrices keep the other modes; fp64 did not gain: the windows are twice as large and the register kernels are already at the coalesced-gather ceiling).
+				// matrices keep the other modes). With 16-bit window-relative indices it also wins in fp64 (cant twin 11.2 -> 9.9 us,
+				// pwtk twin 24.7 -> 23.7 us); fp64 with 32-bit indices ties with csr_vector and is not adopted automatically.
 				auto try_window = [&](bool force) -> int {
 					int G = R ? R : std::max(8, pick_lanes_per_row(mean));
 					if (G != 8 && G != 16 && G != 32 && G != 64)
@@ -879,7 +881,11 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 							max_w = std::max(max_w, b_w[b]);
 						}
 					}
-					if (!force && (with_window * 100 < nb * 95 || mean < 16 || !A->f32 || lnnz < (2L << 20)))
+					// 16-bit window-relative indices need every non-empty block to have a window of at most 65 536 columns
+					bool eligible16 = max_w <= 65536 && lnnz > 0;
+					for (long b = 0; b < nb && eligible16; b++)
+						eligible16 = b_w[b] > 0 || rp[b_row[b + 1]] == rp[b_row[b]];
+					if (!force && (with_window * 100 < nb * 95 || mean < 16 || lnnz < (2L << 20) || !(A->f32 || eligible16)))
 						return 0;
 					A->stream_mode = 4;
 					A->lanes_per_row = G;
@@ -890,7 +896,30 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 						return -1;
 					A->cfg.map = xcd_map_balanced(b_nnz.data(), nb, 1, resolve_remap(A->remap, nb));
 					A->mem_footprint += (3.0 * nb + 1) * 4;
-					snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_WINDOW_g%d_b%ld_w%ld_%s", G, nb, with_window * 100 / nb, pf);
+					// every block has its window and none is wider than 65 536 columns: store the column indices relative to the
+					// window in 16 bits (2 B per non-zero of stream instead of 4) and let go of the int32 array
+					const bool short_idx = eligible16;
+					if (short_idx)
+					{
+						std::vector<unsigned short> c16((size_t) lnnz);
+						#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4)
+						for (long b = 0; b < nb; b++)
+							for (long j = rp[b_row[b]]; j < rp[b_row[b + 1]]; j++)
+								c16[j] = (unsigned short) (ci[j] - b_lo[b]);
+						if (dev_alloc_bytes((void **) &A->d_col16, ((size_t) lnnz + STREAM_SLACK) * 2))
+							return -1;
+						if (hipMemcpy(A->d_col16, c16.data(), (size_t) lnnz * 2, hipMemcpyHostToDevice) != hipSuccess ||
+						    hipMemset(A->d_col16 + lnnz, 0, STREAM_SLACK * 2) != hipSuccess)
+						{
+							set_error("upload of the 16-bit column indices failed");
+							return -1;
+						}
+						(void) hipFree(A->d_col);
+						A->d_col = nullptr;
+						A->mem_footprint -= 2.0 * lnnz;
+					}
+					snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_WINDOW%s_g%d_b%ld_w%ld_%s", short_idx ? "16" : "", G, nb,
+							with_window * 100 / nb, pf);
 					snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_window_kernel");
 					return 1;
 				};
@@ -1179,7 +1208,8 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 			break;
 		case SPMV_MI355X_CSR_STREAM:
 			rc = (A->stream_mode == 4)
-			     ? launch_csr_window(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, A->d_win_row, A->d_win_lo, A->d_win_w,
+			     ? launch_csr_window(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col16 ? (const void *) A->d_col16 : (const void *) A->d_col,
+					A->d_col16 ? 1 : 0, A->d_val, x, y, A->d_win_row, A->d_win_lo, A->d_win_w,
 					A->win_lds_bytes, cfg, st, &grid)
 			     : (A->stream_mode == 3)
 			     ? launch_csr_stream_d(A->f32, A->lanes_per_row, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, cfg, st, &grid)
