@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "p2p"],
                     help="N>1: RCCL allgather of the padded x slices, or grouped send/recv of only the sub-ranges each row "
                          "block reads (same result); auto = time both in the warm-up and keep the faster")
+    ap.add_argument("--partition", default="auto", choices=["auto", "rows", "graph"],
+                    help="N>1: 'rows' = the reference's nnz-balanced contiguous row blocks of A as it is; 'graph' = the same balance "
+                         "cut out of a breadth-first order of the matrix graph (the engine runs on P A P^T; x and y live in that "
+                         "numbering); 'auto' = whichever makes the busiest rank read fewer remote x entries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -182,25 +186,38 @@ def main():
             row_ptr_g = A["row_ptr"]
             blk = A
             r0, r1 = 0, m
-        else:
-            row_ptr_g = H.gen_kkt_row_ptr(N)
+        elif args.partition == "rows":
+            row_ptr_g = H.gen_kkt_row_ptr(N)                # row blocks of A as it is: every rank builds only its own
             m = n = len(row_ptr_g) - 1
             nnz_total = int(row_ptr_g[m])
+        else:
+            A = H.gen_kkt(N)                                # the graph partition looks at the whole structure
+            m = n = A["m"]
+            nnz_total = A["nnz"]
+            row_ptr_g = A["row_ptr"]
     else:
         A = H.gen_named(workload, args.scale)
         m, n, nnz_total, row_ptr_g = A["m"], A["n"], A["nnz"], A["row_ptr"]
         blk = A
         r0, r1 = 0, m
     offsets = None
+    partition_info = None
     if world > 1:
         import spmv_dist as D
-        offsets = D.row_partition(row_ptr_g, world)          # nnz-balanced contiguous row blocks (parallel_util.h:156-184)
-        r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
-        if workload == "nlpkkt240":
+        if workload == "nlpkkt240" and args.partition == "rows":
+            offsets = D.row_partition(row_ptr_g, world)      # nnz-balanced contiguous row blocks (parallel_util.h:156-184)
+            r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
             blk = H.gen_kkt_block(kkt_edge(args.scale), r0, r1)
+            partition_info = {"kind": "rows"}
         else:
-            blk = D.local_block(row_ptr_g, A["col_idx"], A["values"], offsets, rank)
-            del A
+            # deterministic host code on the same matrix: every rank arrives at the same partition without talking
+            part = D.graph_partition(row_ptr_g, A["col_idx"], m, n, world, args.partition)
+            offsets = part.offsets
+            r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
+            blk = D.partition_block(row_ptr_g, A["col_idx"], A["values"], part, rank)
+            partition_info = {"kind": part.kind, "remote_x_entries_per_rank": [int(v) for v in part.volume],
+                              "considered_max_remote_x_entries": part.considered}
+            del A, part
         assert m == n, "row-partitioned allgather(x) assumes a square matrix (x slices follow the row blocks)"
         padded = D.padded_len(offsets)
         D.to_padded_columns(blk["col_idx"], offsets, padded)   # x lives as `world` slices padded to a common length
@@ -433,7 +450,7 @@ def main():
         "config": {"workload": f"{workload} (synthetic twin)" + ("" if args.scale == 1.0 else f" scale={args.scale}"),
                    "format": mats[0].format_name, "rows": int(m), "cols": int(n), "nnz": int(nnz_total),
                    "parallelism": "single GPU" if world == 1 else
-                   f"row-partitioned x{world}, RCCL {'send/recv of the needed x ranges' if use_p2p else 'allgather(x)'} "
+                   f"row-partitioned x{world} ({'row blocks of A' if partition_info['kind'] == 'rows' else 'row blocks of P A P^T, P = breadth-first slabs'}), RCCL {'send/recv of the needed x ranges' if use_p2p else 'allgather(x)'} "
                    f"{'overlapped with local columns' if args.overlap else 'then SpMV'}"},
         "hbm_gbps_algorithmic": round(B_alg / (ms_per_step * 1e-3) / 1e9, 2),
         "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 2),
@@ -444,6 +461,7 @@ def main():
                      "algorithmic_bytes_per_launch": int(B_alg_local)},
         "check_max_err_over_abs_row": max_rel,
         "exchange": exchange_info,
+        "partition": partition_info,
         "breakdown_ms": None if world == 1 else {"exchange_alone": round(comm_only_ms, 4), "kernels_alone": round(kernels_only_ms, 4),
                                                  "overlap_efficiency": round((comm_only_ms + kernels_only_ms) / ms_per_step, 3)},
         "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t_conv, 2)},

@@ -91,6 +91,24 @@ int  spmv_host_remap_columns(int32_t * col_idx, long nnz, const long * offsets, 
  * (hi[q] <= lo[q]: none). Used to trim the x exchange to what a row block really reads. */
 int  spmv_host_column_ranges(const int32_t * col_idx, long nnz, long padded, long parts, long * lo, long * hi);
 
+/* Communication-aware row partition for the multi-GPU SpMV (square matrices; host/graph_partition.cpp). The reference has
+ * no counterpart: its threads share x (csr.cpp:140 partitions rows only for load balance, lib/parallel_util.h:156-184).
+ *   bfs_order          order[m]: vertices in breadth-first order from a pseudo-peripheral vertex, every component
+ *   owners_from_order  owner[v] in [0,parts): nnz-balanced contiguous cuts of that order
+ *   partition_volume   volume[p]: distinct x entries part p reads from other parts under `owner`
+ *   partition_layout   perm[m] (new -> old) and offsets[parts+1]: parts in order; inside a part first the vertices other
+ *                      parts read (grouped by the lowest reader), then the interior, each group in original order
+ *   permuted_block     rows [row_begin,row_end) of P A P^T (inv = old -> new) as a local CSR with columns ascending in
+ *                      the new numbering; free with spmv_host_csr_free */
+int  spmv_host_bfs_order(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, int32_t * order);
+int  spmv_host_owners_from_order(const int32_t * row_ptr, long m, const int32_t * order, long parts, int32_t * owner);
+int  spmv_host_partition_volume(const int32_t * row_ptr, const int32_t * col_idx, long m, const int32_t * owner, long parts,
+		long * volume);
+int  spmv_host_partition_layout(const int32_t * row_ptr, const int32_t * col_idx, long m, const int32_t * owner, long parts,
+		int32_t * perm, long * offsets);
+int  spmv_host_permuted_block(const int32_t * row_ptr, const int32_t * col_idx, const double * values, long m,
+		const int32_t * perm, const int32_t * inv, long row_begin, long row_end, spmv_host_csr * out);
+
 /* Structural features the reference uses to describe a matrix (lib/storage_formats/csr_util/csr_util_gen.c:437-447,
  * 596-695,961): out[0..6] = avg nnz/row, std nnz/row, avg bandwidth scaled by n, skew = (max-avg)/avg,
  * avg_num_neighbours (window 1), cross_row_similarity (window 1), max nnz/row. */

@@ -37,6 +37,12 @@ int gen_kkt_row_ptr(long N, int32_t * row_ptr, long * m_out, long * nnz_out);
 int gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out);
 int column_ranges(const int32_t * col_idx, long nnz, long padded, long parts, long * lo, long * hi);
 int remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, long padded);
+int bfs_order(const int32_t * rp, const int32_t * ci, long m, long n, int32_t * order);
+int owners_from_order(const int32_t * rp, long m, const int32_t * order, long parts, int32_t * owner);
+int partition_volume(const int32_t * rp, const int32_t * ci, long m, const int32_t * owner, long parts, long * volume);
+int partition_layout(const int32_t * rp, const int32_t * ci, long m, const int32_t * owner, long parts, int32_t * perm, long * offsets);
+int permuted_block(const int32_t * rp, const int32_t * ci, const double * va, long m, const int32_t * perm, const int32_t * inv,
+		long r0, long r1, spmv_host_csr * out);
 int csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out7);
 
 // counter-based generator: independent stream per (seed, row) so the generators are parallel AND deterministic

@@ -142,6 +142,38 @@ spmv_host_column_ranges(const int32_t * col_idx, long nnz, long padded, long par
 	return column_ranges(col_idx, nnz, padded, parts, lo, hi);
 }
 
+int
+spmv_host_bfs_order(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, int32_t * order)
+{
+	return bfs_order(row_ptr, col_idx, m, n, order);
+}
+
+int
+spmv_host_owners_from_order(const int32_t * row_ptr, long m, const int32_t * order, long parts, int32_t * owner)
+{
+	return owners_from_order(row_ptr, m, order, parts, owner);
+}
+
+int
+spmv_host_partition_volume(const int32_t * row_ptr, const int32_t * col_idx, long m, const int32_t * owner, long parts, long * volume)
+{
+	return partition_volume(row_ptr, col_idx, m, owner, parts, volume);
+}
+
+int
+spmv_host_partition_layout(const int32_t * row_ptr, const int32_t * col_idx, long m, const int32_t * owner, long parts,
+		int32_t * perm, long * offsets)
+{
+	return partition_layout(row_ptr, col_idx, m, owner, parts, perm, offsets);
+}
+
+int
+spmv_host_permuted_block(const int32_t * row_ptr, const int32_t * col_idx, const double * values, long m, const int32_t * perm,
+		const int32_t * inv, long row_begin, long row_end, spmv_host_csr * out)
+{
+	return permuted_block(row_ptr, col_idx, values, m, perm, inv, row_begin, row_end, out);
+}
+
 // Twin strings of benchmark_code/BENCH/config.sh:402,413,430,449 (seed 14 in every one).
 int
 spmv_host_gen_named(const char * name, double scale, spmv_host_csr * out)

@@ -27,6 +27,58 @@ def row_partition(row_ptr, world):
     return offsets
 
 
+class Partition:
+    """Which rank owns which rows/x entries. kind "rows": the reference's contiguous nnz-balanced row blocks of A as it is
+    (perm None). kind "graph": slabs of a breadth-first order of the matrix graph — the engine then works on P A P^T, whose
+    row blocks are contiguous again: perm[new] = old, inv[old] = new; x and y live in the new numbering
+    (x_new = x_old[perm], y_old[perm] = y_new). volume[p] = x entries rank p reads from its peers."""
+
+    def __init__(self, kind, offsets, volume, perm=None):
+        self.kind, self.offsets, self.volume, self.perm = kind, np.asarray(offsets, np.int64), np.asarray(volume, np.int64), perm
+        self.inv = None
+        self.considered = {kind: int(self.volume.max()) if len(self.volume) else 0}      # max remote x entries of each candidate looked at
+        if perm is not None:
+            self.inv = np.empty(len(perm), np.int32)
+            self.inv[perm] = np.arange(len(perm), dtype=np.int32)
+
+
+def graph_partition(row_ptr, col_idx, m, n, world, mode="auto"):
+    """Choose the row partition of a square matrix for `world` GPUs (host/graph_partition.cpp).
+
+    "rows"  : row_partition() — what the reference does for its threads (parallel_util.h:156-184)
+    "graph" : the same nnz balance cut out of a breadth-first order; inside a rank the x entries its peers read come first
+    "auto"  : whichever makes the busiest rank read fewer remote x entries (every rank computes the same answer)"""
+    assert mode in ("auto", "rows", "graph")
+    rows = None
+    if mode in ("auto", "rows") or m != n:
+        offs = row_partition(row_ptr, world)
+        owner = np.repeat(np.arange(world, dtype=np.int32), np.diff(offs))
+        vol = H.partition_volume(row_ptr, col_idx, owner, world) if m == n else np.zeros(world, np.int64)
+        rows = Partition("rows", offs, vol)
+        if mode == "rows" or m != n or world == 1:
+            return rows
+    order = H.bfs_order(row_ptr, col_idx, m, n)
+    owner = H.owners_from_order(row_ptr, order, world)
+    del order
+    vol = H.partition_volume(row_ptr, col_idx, owner, world)
+    if mode == "auto" and int(vol.max()) >= int(rows.volume.max()):
+        rows.considered["graph"] = int(vol.max())
+        return rows
+    perm, offs = H.partition_layout(row_ptr, col_idx, owner, world)
+    part = Partition("graph", offs, vol, perm)
+    if rows is not None:
+        part.considered["rows"] = int(rows.volume.max())
+    return part
+
+
+def partition_block(row_ptr, col_idx, values, part, rank):
+    """Rows of `rank` under `part` as a local CSR (row_ptr from 0, column indices GLOBAL in the partition's numbering)."""
+    if part.perm is None:
+        return local_block(row_ptr, col_idx, values, part.offsets, rank)
+    blk = H.permuted_block(row_ptr, col_idx, values, part.perm, part.inv, int(part.offsets[rank]), int(part.offsets[rank + 1]))
+    return dict(m=blk["m"], nnz=blk["nnz"], row_ptr=blk["row_ptr"], col_idx=blk["col_idx"], values=blk["values"])
+
+
 def padded_len(offsets, align=64):
     return int((int(np.diff(offsets).max()) + align - 1) // align * align) if len(offsets) > 1 else 0
 

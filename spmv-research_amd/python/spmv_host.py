@@ -13,6 +13,8 @@ SYMBOLS = [
     "spmv_host_mtx_write_csr", "spmv_host_partition_iterations", "spmv_host_partition_prefix_sums",
     "spmv_host_csr_free", "spmv_host_gen_twin", "spmv_host_gen_named", "spmv_host_gen_kkt", "spmv_host_csr_features",
     "spmv_host_gen_kkt_row_ptr", "spmv_host_gen_kkt_block", "spmv_host_remap_columns", "spmv_host_column_ranges",
+    "spmv_host_bfs_order", "spmv_host_owners_from_order", "spmv_host_partition_volume", "spmv_host_partition_layout",
+    "spmv_host_permuted_block",
 ]
 
 
@@ -178,6 +180,51 @@ def column_ranges(col_idx, padded, parts):
     lo = np.where(hi > lo, lo, 0)
     hi = np.where(hi > lo, hi, 0)
     return lo, hi
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a)
+    assert a.dtype == np.int32
+    return a
+
+
+def bfs_order(row_ptr, col_idx, m, n):
+    """Vertices of the matrix graph in breadth-first order from a pseudo-peripheral vertex (graph_partition.cpp)."""
+    order = np.zeros(m, np.int32)
+    _check(lib().spmv_host_bfs_order(_p(_i32(row_ptr)), _p(_i32(col_idx)), C.c_long(m), C.c_long(n), _p(order)))
+    return order
+
+
+def owners_from_order(row_ptr, order, parts):
+    owner = np.zeros(len(order), np.int32)
+    _check(lib().spmv_host_owners_from_order(_p(_i32(row_ptr)), C.c_long(len(order)), _p(_i32(order)), C.c_long(parts), _p(owner)))
+    return owner
+
+
+def partition_volume(row_ptr, col_idx, owner, parts):
+    """volume[p] = distinct x entries part p reads from other parts."""
+    vol = np.zeros(parts, np.int64)
+    _check(lib().spmv_host_partition_volume(_p(_i32(row_ptr)), _p(_i32(col_idx)), C.c_long(len(owner)), _p(_i32(owner)),
+                                            C.c_long(parts), _p(vol)))
+    return vol
+
+
+def partition_layout(row_ptr, col_idx, owner, parts):
+    """(perm new->old, offsets[parts+1]): boundary vertices first inside every part, original order inside a group."""
+    perm = np.zeros(len(owner), np.int32)
+    offsets = np.zeros(parts + 1, np.int64)
+    _check(lib().spmv_host_partition_layout(_p(_i32(row_ptr)), _p(_i32(col_idx)), C.c_long(len(owner)), _p(_i32(owner)),
+                                            C.c_long(parts), _p(perm), _p(offsets)))
+    return perm, offsets
+
+
+def permuted_block(row_ptr, col_idx, values, perm, inv, r0, r1):
+    """Rows [r0,r1) of P A P^T as a local CSR (columns in the new numbering, ascending)."""
+    values = np.ascontiguousarray(values, np.float64)
+    csr = _Csr()
+    _check(lib().spmv_host_permuted_block(_p(_i32(row_ptr)), _p(_i32(col_idx)), _p(values), C.c_long(len(perm)), _p(_i32(perm)),
+                                          _p(_i32(inv)), C.c_long(r0), C.c_long(r1), C.byref(csr)))
+    return _take_csr(csr)
 
 
 FEATURES = ("avg_nnz_per_row", "std_nnz_per_row", "avg_bw_scaled", "skew", "avg_num_neighbours",

@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="rows"):
     for p in (os.path.join(ROOT, "spmv-research_amd", "python"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     import oracle as orc
@@ -25,10 +25,16 @@ def _worker(rank, world, port, q):
     try:
         A = H.gen_kkt(9)                                           # same matrix on every rank (deterministic)
         m = n = A["m"]
-        x = np.random.default_rng(14).uniform(-1, 1, n)
-        off = D.row_partition(A["row_ptr"], world)
+        x_orig = np.random.default_rng(14).uniform(-1, 1, n)
+        part = D.graph_partition(A["row_ptr"], A["col_idx"], m, n, world, mode)
+        assert part.kind == mode
+        # the graph partition works on P A P^T: x and y live in the new numbering
+        x = x_orig if part.perm is None else x_orig[part.perm]
+        off = part.offsets
+        if mode == "rows":
+            np.testing.assert_array_equal(off, D.row_partition(A["row_ptr"], world))
         r0, r1 = int(off[rank]), int(off[rank + 1])
-        blk = D.local_block(A["row_ptr"], A["col_idx"], A["values"], off, rank)
+        blk = D.partition_block(A["row_ptr"], A["col_idx"], A["values"], part, rank)
         padded = D.padded_len(off)
         D.to_padded_columns(blk["col_idx"], off, padded)
         x_full = torch.zeros(world * padded, dtype=torch.float64)
@@ -75,19 +81,22 @@ def _worker(rank, world, port, q):
         dist.all_gather(ys, ypad)
         if rank == 0:
             y_all = torch.cat([ys[p][:int(off[p + 1] - off[p])] for p in range(world)]).numpy()
-            y_ref = orc.csr_spmv(A["row_ptr"], A["col_idx"], A["values"], x)
-            absrow = orc.csr_spmv(A["row_ptr"], A["col_idx"], np.abs(A["values"]), np.abs(x))
+            y_ref = orc.csr_spmv(A["row_ptr"], A["col_idx"], A["values"], x_orig)
+            absrow = orc.csr_spmv(A["row_ptr"], A["col_idx"], np.abs(A["values"]), np.abs(x_orig))
+            if part.perm is not None:
+                y_ref, absrow = y_ref[part.perm], absrow[part.perm]
             q.put(float(np.max(np.abs(y_all - y_ref) / absrow)))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["rows", "graph"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_row_partition_allgather_gloo(world):
+def test_row_partition_allgather_gloo(world, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -1,0 +1,104 @@
+"""Host logic of the communication-aware row partition (host/graph_partition.cpp, spmv_dist.graph_partition): the engine
+runs on P A P^T, so P must be a permutation, the blocks must be exactly the permuted rows, and the layout must keep what
+peers read in a prefix of every slice. scipy is the independent check of the permutation algebra."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import spmv_dist as D
+import spmv_host as H
+
+
+def _csr(A):
+    return sp.csr_matrix((A["values"], A["col_idx"], A["row_ptr"]), shape=(A["m"], A["n"]))
+
+
+def _cases():
+    yield "kkt9", H.gen_kkt(9)
+    yield "cant_twin", H.gen_named("cant", 0.02)
+    rng = np.random.default_rng(3)                       # two components + isolated vertices + an empty row
+    m = 300
+    rows = rng.integers(0, 140, 900); cols = rng.integers(0, 140, 900)
+    r2 = rng.integers(150, 290, 700); c2 = rng.integers(150, 290, 700)
+    R = np.concatenate([rows, cols, r2, c2]); Cc = np.concatenate([cols, rows, c2, r2])
+    S = sp.coo_matrix((rng.uniform(-1, 1, len(R)), (R, Cc)), shape=(m, m)).tocsr()
+    S.sum_duplicates(); S.sort_indices()
+    yield "two_components", dict(m=m, n=m, nnz=S.nnz, row_ptr=S.indptr.astype(np.int32), col_idx=S.indices.astype(np.int32),
+                                 values=S.data.astype(np.float64))
+
+
+@pytest.mark.parametrize("name,A", list(_cases()), ids=[c[0] for c in _cases()])
+@pytest.mark.parametrize("world", [1, 2, 5])
+def test_graph_partition_is_a_permutation_of_the_same_operator(name, A, world):
+    m = A["m"]
+    order = H.bfs_order(A["row_ptr"], A["col_idx"], m, m)
+    assert sorted(order.tolist()) == list(range(m))
+    part = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, world, "graph" if world > 1 else "auto")
+    if world == 1:
+        assert part.kind == "rows" and part.perm is None
+        return
+    perm, inv, off = part.perm, part.inv, part.offsets
+    assert sorted(perm.tolist()) == list(range(m)) and off[0] == 0 and off[-1] == m and np.all(np.diff(off) >= 0)
+    np.testing.assert_array_equal(perm[inv], np.arange(m))
+    S = _csr(A)
+    P = S[perm][:, perm].tocsr()
+    P.sort_indices()
+    x = np.random.default_rng(1).uniform(-1, 1, m)
+    y_old = S @ x
+    owner_new = np.repeat(np.arange(world), np.diff(off))
+    for r in range(world):
+        blk = D.partition_block(A["row_ptr"], A["col_idx"], A["values"], part, r)
+        r0, r1 = int(off[r]), int(off[r + 1])
+        assert blk["m"] == r1 - r0
+        np.testing.assert_array_equal(blk["row_ptr"], P.indptr[r0:r1 + 1] - P.indptr[r0])
+        np.testing.assert_array_equal(blk["col_idx"], P.indices[P.indptr[r0]:P.indptr[r1]])
+        np.testing.assert_array_equal(blk["values"], P.data[P.indptr[r0]:P.indptr[r1]])
+        B = sp.csr_matrix((blk["values"], blk["col_idx"], blk["row_ptr"]), shape=(blk["m"], m))
+        np.testing.assert_allclose(B @ x[perm], y_old[perm][r0:r1], rtol=0, atol=1e-12)
+        # volume = distinct remote columns of the block
+        remote = np.unique(blk["col_idx"][owner_new[blk["col_idx"]] != r])
+        assert part.volume[r] == len(remote)
+    # layout: inside every slice, everything a peer reads sits before everything nobody else reads
+    read_by_peer = np.zeros(m, bool)
+    rows_new = np.repeat(np.arange(m), np.diff(P.indptr))
+    cross = owner_new[rows_new] != owner_new[P.indices]
+    read_by_peer[P.indices[cross]] = True
+    for r in range(world):
+        seg = read_by_peer[off[r]:off[r + 1]]
+        k = int(seg.sum())
+        assert seg[:k].all() and not seg[k:].any()
+        # and each group keeps the matrix's original order
+        assert np.all(np.diff(perm[off[r] + k:off[r + 1]]) > 0)
+
+
+def test_auto_picks_the_partition_with_less_exchange():
+    A = H.gen_kkt(12)
+    m = A["m"]
+    rows = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, 4, "rows")
+    graph = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, 4, "graph")
+    auto = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, 4, "auto")
+    assert graph.volume.max() < rows.volume.max()               # KKT coupling: constraint rows read all of H's x
+    assert auto.kind == "graph"
+    np.testing.assert_array_equal(auto.perm, graph.perm)
+    # a banded matrix is already in a good order: nothing to gain, stay with the reference's row blocks
+    B = H.gen_named("cant", 0.05)
+    auto = D.graph_partition(B["row_ptr"], B["col_idx"], B["m"], B["m"], 4, "auto")
+    rows = D.graph_partition(B["row_ptr"], B["col_idx"], B["m"], B["m"], 4, "rows")
+    assert auto.volume.max() <= rows.volume.max()
+
+
+def test_non_square_falls_back_to_row_blocks():
+    rp = np.array([0, 2, 3, 5], np.int32)
+    ci = np.array([0, 4, 1, 2, 3], np.int32)
+    part = D.graph_partition(rp, ci, 3, 5, 2, "auto")
+    assert part.kind == "rows" and part.perm is None
+    with pytest.raises(H.HostError, match="square"):
+        H.bfs_order(rp, ci, 3, 5)
+
+
+def test_balance_of_the_graph_partition():
+    A = H.gen_kkt(14)
+    m, nnz = A["m"], A["nnz"]
+    part = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, 8, "graph")
+    per = np.array([D.partition_block(A["row_ptr"], A["col_idx"], A["values"], part, r)["nnz"] for r in range(8)])
+    assert per.sum() == nnz and per.max() <= 1.1 * nnz / 8
