@@ -63,6 +63,11 @@ def parse():
                     help="N>1: 'rows' = the reference's nnz-balanced contiguous row blocks of A as it is; 'graph' = the same balance "
                          "cut out of a breadth-first order of the matrix graph (the engine runs on P A P^T; x and y live in that "
                          "numbering); 'auto' = whichever makes the busiest rank read fewer remote x entries")
+    ap.add_argument("--layout", default="auto", choices=["auto", "original", "padded"],
+                    help="N>1 with the graph partition: 'original' = every rank keeps a full-length x in the matrix's ORIGINAL "
+                         "numbering (rows keep the column patterns the format compresses) and the halo moves by pack -> send/recv -> "
+                         "scatter; 'padded' = P A P^T with x as padded slices exchanged in place; 'auto' = original when its "
+                         "exchange validates on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -202,6 +207,10 @@ def main():
         r0, r1 = 0, m
     offsets = None
     partition_info = None
+    layout = "padded"                                       # N>1: how x is laid out on a rank (see --layout)
+    packed = None
+    blk_pair = None
+    x_host = np.random.default_rng(14).uniform(-1.0, 1.0, n).astype(np_dtype)   # global x (same on every rank)
     if world > 1:
         import spmv_dist as D
         if workload == "nlpkkt240" and args.partition == "rows":
@@ -217,11 +226,46 @@ def main():
             blk = D.partition_block(row_ptr_g, A["col_idx"], A["values"], part, rank)
             partition_info = {"kind": part.kind, "remote_x_entries_per_rank": [int(v) for v in part.volume],
                               "considered_max_remote_x_entries": part.considered}
+            if part.kind == "graph" and args.layout != "padded":
+                # original-numbering layout: validate its exchange BEFORE anything is built on it; all ranks take the same branch
+                owner = part.owner()
+                ok = 1
+                try:
+                    send, recv = H.halo_lists(row_ptr_g, A["col_idx"], owner, world, rank)
+                    mine = np.flatnonzero(owner == rank)
+                    x_orig = torch.zeros(n, dtype=t_dtype, device="cuda")
+                    x_orig[torch.from_numpy(mine).cuda()] = torch.from_numpy(x_host[mine]).cuda()
+                    packed = D.PackedExchange(dist, torch, x_orig, send, recv, rank, world)
+                    packed.finish(packed.start())
+                    torch.cuda.synchronize()
+                    want = np.concatenate([x_host[l] for l in recv]) if packed.recv_elems else np.zeros(0, np_dtype)
+                    if not np.array_equal(x_orig[packed.recv_idx].cpu().numpy(), want):
+                        ok = 0
+                except Exception as e:
+                    ok = 0
+                    partition_info["packed_exchange_error"] = repr(e)[:200]
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    layout = "original"
+                    blk, mine2 = D.original_block(row_ptr_g, A["col_idx"], A["values"], owner, rank)
+                    assert np.array_equal(mine, mine2)
+                    if args.overlap:
+                        blk_pair = D.split_by_owner(blk, owner, rank)
+                elif args.layout == "original":
+                    raise SystemExit("--layout original: the packed halo exchange did not validate on every rank")
+                else:
+                    packed = None
+                del owner
+            partition_info["layout"] = layout
             del A, part
         assert m == n, "row-partitioned allgather(x) assumes a square matrix (x slices follow the row blocks)"
-        padded = D.padded_len(offsets)
-        D.to_padded_columns(blk["col_idx"], offsets, padded)   # x lives as `world` slices padded to a common length
-        n_x = padded * world
+        if layout == "original":
+            padded, n_x = n, n                              # full-length x in the original numbering, original column indices
+        else:
+            padded = D.padded_len(offsets)
+            D.to_padded_columns(blk["col_idx"], offsets, padded)   # x lives as `world` slices padded to a common length
+            n_x = padded * world
     else:
         padded = n
         n_x = n
@@ -232,6 +276,9 @@ def main():
     t_conv = time.time()
     if world == 1:
         mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype, **opts)]
+    elif layout == "original" and args.overlap:
+        mats = [E.Matrix(b["row_ptr"], b["col_idx"], b["values"], lm, n_x, fmt, np_dtype, **opts) for b in blk_pair]
+        blk_pair = None
     elif args.overlap:
         c0, c1 = rank * padded, rank * padded + (r1 - r0)
         mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype,
@@ -242,12 +289,12 @@ def main():
         mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype, **opts)]
     t_conv = time.time() - t_conv
 
-    rng = np.random.default_rng(14)
-    x_host = rng.uniform(-1.0, 1.0, n).astype(np_dtype)       # global x (same on every rank)
-    x_full = torch.zeros(n_x, dtype=t_dtype, device="cuda")
+    x_full = x_orig if layout == "original" else torch.zeros(n_x, dtype=t_dtype, device="cuda")
     if world == 1:
         x_full.copy_(torch.from_numpy(x_host))
         x_loc = x_full
+    elif layout == "original":
+        x_loc = x_full                                           # own entries already in place (validated above)
     else:
         x_loc = x_full[rank * padded:(rank + 1) * padded]         # in-place allgather: own slice lives inside x_full
         x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
@@ -264,6 +311,13 @@ def main():
     def step():
         if world == 1:
             mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
+            return
+        if layout == "original":
+            reqs = packed.start()                               # pack + grouped send/recv of the halo
+            if args.overlap:
+                mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)      # columns this rank owns, meanwhile
+            packed.finish(reqs)                                 # wait + scatter to the original positions
+            mats[-1].spmv_device(x_full.data_ptr(), y.data_ptr(), 1 if args.overlap else 0, sp)
             return
         if use_p2p:
             reqs = exch.start()
@@ -285,7 +339,10 @@ def main():
         torch.cuda.synchronize()
 
     exchange_info = None
-    if world > 1:
+    if world > 1 and layout == "original":
+        exchange_info = {"chosen": "packed halo p2p", "recv_x_entries": packed.recv_elems, "send_x_entries": packed.send_elems,
+                         "recv_max_from_one_peer": packed.recv_max_from_one_peer}
+    if world > 1 and layout == "padded":
         # one untimed exchange, checked: every rank must end up with the same padded x. If the in-place form (send buffer
         # = own slice of the receive buffer) is not honoured by the backend, fall back to a separate send buffer.
         import spmv_dist as D
@@ -363,6 +420,9 @@ def main():
     if world > 1:
         # untimed breakdown for the scaling report: the exchange alone and the two kernels alone
         def comm_only():
+            if layout == "original":
+                packed.finish(packed.start())
+                return
             for r in (exch.start() if use_p2p else [dist.all_gather_into_tensor(x_full, x_send, async_op=True)]):
                 r.wait()
 
@@ -424,7 +484,7 @@ def main():
     rp, ci, va = blk["row_ptr"], blk["col_idx"], blk["values"]
     for i in samp:
         cols = ci[rp[i]:rp[i + 1]].astype(np.int64)
-        if world > 1:
+        if world > 1 and layout == "padded":
             p = cols // padded
             cols = offsets[p] + (cols - p * padded)
         vals = va[rp[i]:rp[i + 1]].astype(np_dtype).astype(np.float64)
@@ -450,7 +510,8 @@ def main():
         "config": {"workload": f"{workload} (synthetic twin)" + ("" if args.scale == 1.0 else f" scale={args.scale}"),
                    "format": mats[0].format_name, "rows": int(m), "cols": int(n), "nnz": int(nnz_total),
                    "parallelism": "single GPU" if world == 1 else
-                   f"row-partitioned x{world} ({'row blocks of A' if partition_info['kind'] == 'rows' else 'row blocks of P A P^T, P = breadth-first slabs'}), RCCL {'send/recv of the needed x ranges' if use_p2p else 'allgather(x)'} "
+                   f"row-partitioned x{world} ({'row blocks of A' if partition_info['kind'] == 'rows' else 'breadth-first slabs of the matrix graph, x in original numbering' if layout == 'original' else 'row blocks of P A P^T, P = breadth-first slabs'}), "
+                   f"RCCL {'packed halo send/recv' if layout == 'original' else 'send/recv of the needed x ranges' if use_p2p else 'allgather(x)'} "
                    f"{'overlapped with local columns' if args.overlap else 'then SpMV'}"},
         "hbm_gbps_algorithmic": round(B_alg / (ms_per_step * 1e-3) / 1e9, 2),
         "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 2),

@@ -109,6 +109,13 @@ int  spmv_host_partition_layout(const int32_t * row_ptr, const int32_t * col_idx
 int  spmv_host_permuted_block(const int32_t * row_ptr, const int32_t * col_idx, const double * values, long m,
 		const int32_t * perm, const int32_t * inv, long row_begin, long row_end, spmv_host_csr * out);
 
+/* Halo index lists of `rank` under an owner map, in ORIGINAL vertex numbers, every list ascending: send (vertices of `rank`
+ * that rows of part q read) and recv (vertices of part q that rows of `rank` read), concatenated over q with
+ * offsets[parts+1]. send[q] on rank p and recv[p] on rank q are the same set, so packed buffers need no header. The two
+ * lists are malloc'ed; free with spmv_host_free. */
+int  spmv_host_halo_lists(const int32_t * row_ptr, const int32_t * col_idx, long m, const int32_t * owner, long parts, long rank,
+		long * send_offsets, int32_t ** send_list, long * recv_offsets, int32_t ** recv_list);
+
 /* Structural features the reference uses to describe a matrix (lib/storage_formats/csr_util/csr_util_gen.c:437-447,
  * 596-695,961): out[0..6] = avg nnz/row, std nnz/row, avg bandwidth scaled by n, skew = (max-avg)/avg,
  * avg_num_neighbours (window 1), cross_row_similarity (window 1), max nnz/row. */

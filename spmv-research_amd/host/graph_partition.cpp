@@ -240,3 +240,90 @@ permuted_block(const int32_t * rp, const int32_t * ci, const double * va, long m
 }
 
 }  // namespace spmv_host
+
+namespace spmv_host {
+
+// Halo index lists of one rank under an owner map, in ORIGINAL vertex numbers, each list ascending:
+//   send[q] = vertices owned by `rank` that rows owned by q read      (what `rank` packs and sends to q)
+//   recv[q] = vertices owned by q that rows owned by `rank` read      (where what q sends is scattered to)
+// send[q] of rank p and recv[p] of rank q are the same set by construction, so the packed buffers need no header.
+int
+halo_lists(const int32_t * rp, const int32_t * ci, long m, const int32_t * owner, long parts, long rank,
+		long * send_offsets, int32_t ** send_list, long * recv_offsets, int32_t ** recv_list)
+{
+	if (rank < 0 || rank >= parts)
+	{
+		set_error("halo_lists: rank %ld outside [0,%ld)", rank, parts);
+		return 1;
+	}
+	const long words = (m + 63) / 64;
+	std::vector<unsigned long long> sbits((size_t) (parts * words), 0ull), rbits((size_t) words, 0ull);
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4096)
+	for (long i = 0; i < m; i++)
+	{
+		const long q = owner[i];
+		if (q == rank)
+		{
+			for (long j = rp[i]; j < rp[i + 1]; j++)
+			{
+				const long c = ci[j];
+				if (owner[c] != rank)
+				{
+					const unsigned long long bit = 1ull << (c & 63);
+					if (!(__atomic_load_n(&rbits[c >> 6], __ATOMIC_RELAXED) & bit))
+						__atomic_fetch_or(&rbits[c >> 6], bit, __ATOMIC_RELAXED);
+				}
+			}
+		}
+		else
+		{
+			unsigned long long * b = sbits.data() + q * words;
+			for (long j = rp[i]; j < rp[i + 1]; j++)
+			{
+				const long c = ci[j];
+				if (owner[c] == rank)
+				{
+					const unsigned long long bit = 1ull << (c & 63);
+					if (!(__atomic_load_n(&b[c >> 6], __ATOMIC_RELAXED) & bit))
+						__atomic_fetch_or(&b[c >> 6], bit, __ATOMIC_RELAXED);
+				}
+			}
+		}
+	}
+	std::vector<int32_t> s, r;
+	std::vector<std::vector<int32_t>> rq((size_t) parts);
+	for (long w = 0; w < words; w++)
+		for (unsigned long long v = rbits[w]; v; v &= v - 1)
+		{
+			const long c = w * 64 + __builtin_ctzll(v);
+			rq[(size_t) owner[c]].push_back((int32_t) c);
+		}
+	send_offsets[0] = recv_offsets[0] = 0;
+	for (long q = 0; q < parts; q++)
+	{
+		const unsigned long long * b = sbits.data() + q * words;
+		for (long w = 0; w < words; w++)
+			for (unsigned long long v = b[w]; v; v &= v - 1)
+				s.push_back((int32_t) (w * 64 + __builtin_ctzll(v)));
+		send_offsets[q + 1] = (long) s.size();
+		r.insert(r.end(), rq[(size_t) q].begin(), rq[(size_t) q].end());
+		recv_offsets[q + 1] = (long) r.size();
+	}
+	*send_list = (int32_t *) malloc(std::max<size_t>(s.size(), 1) * sizeof(int32_t));
+	*recv_list = (int32_t *) malloc(std::max<size_t>(r.size(), 1) * sizeof(int32_t));
+	if (!*send_list || !*recv_list)
+	{
+		free(*send_list);
+		free(*recv_list);
+		*send_list = *recv_list = nullptr;
+		set_error("halo_lists: out of memory");
+		return 1;
+	}
+	if (!s.empty())
+		memcpy(*send_list, s.data(), s.size() * sizeof(int32_t));
+	if (!r.empty())
+		memcpy(*recv_list, r.data(), r.size() * sizeof(int32_t));
+	return 0;
+}
+
+}  // namespace spmv_host

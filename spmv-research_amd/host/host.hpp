@@ -43,6 +43,8 @@ int partition_volume(const int32_t * rp, const int32_t * ci, long m, const int32
 int partition_layout(const int32_t * rp, const int32_t * ci, long m, const int32_t * owner, long parts, int32_t * perm, long * offsets);
 int permuted_block(const int32_t * rp, const int32_t * ci, const double * va, long m, const int32_t * perm, const int32_t * inv,
 		long r0, long r1, spmv_host_csr * out);
+int halo_lists(const int32_t * rp, const int32_t * ci, long m, const int32_t * owner, long parts, long rank,
+		long * send_offsets, int32_t ** send_list, long * recv_offsets, int32_t ** recv_list);
 int csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out7);
 
 // counter-based generator: independent stream per (seed, row) so the generators are parallel AND deterministic

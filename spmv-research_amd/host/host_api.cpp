@@ -174,6 +174,13 @@ spmv_host_permuted_block(const int32_t * row_ptr, const int32_t * col_idx, const
 	return permuted_block(row_ptr, col_idx, values, m, perm, inv, row_begin, row_end, out);
 }
 
+int
+spmv_host_halo_lists(const int32_t * row_ptr, const int32_t * col_idx, long m, const int32_t * owner, long parts, long rank,
+		long * send_offsets, int32_t ** send_list, long * recv_offsets, int32_t ** recv_list)
+{
+	return halo_lists(row_ptr, col_idx, m, owner, parts, rank, send_offsets, send_list, recv_offsets, recv_list);
+}
+
 // Twin strings of benchmark_code/BENCH/config.sh:402,413,430,449 (seed 14 in every one).
 int
 spmv_host_gen_named(const char * name, double scale, spmv_host_csr * out)

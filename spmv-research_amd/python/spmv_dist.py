@@ -42,6 +42,16 @@ class Partition:
             self.inv[perm] = np.arange(len(perm), dtype=np.int32)
 
 
+    def owner(self):
+        """owner[v] of every ORIGINAL vertex v."""
+        by_new = np.repeat(np.arange(len(self.offsets) - 1, dtype=np.int32), np.diff(self.offsets))
+        if self.perm is None:
+            return by_new
+        out = np.empty(len(self.perm), np.int32)
+        out[self.perm] = by_new
+        return out
+
+
 def graph_partition(row_ptr, col_idx, m, n, world, mode="auto"):
     """Choose the row partition of a square matrix for `world` GPUs (host/graph_partition.cpp).
 
@@ -77,6 +87,80 @@ def partition_block(row_ptr, col_idx, values, part, rank):
         return local_block(row_ptr, col_idx, values, part.offsets, rank)
     blk = H.permuted_block(row_ptr, col_idx, values, part.perm, part.inv, int(part.offsets[rank]), int(part.offsets[rank + 1]))
     return dict(m=blk["m"], nnz=blk["nnz"], row_ptr=blk["row_ptr"], col_idx=blk["col_idx"], values=blk["values"])
+
+
+def original_block(row_ptr, col_idx, values, owner, rank):
+    """Rows owned by `rank` in ascending ORIGINAL order as a local CSR whose column indices stay the ORIGINAL ones (the
+    "original numbering" layout: x is a full-length buffer on every rank, see PackedExchange). Returns (block, rows)."""
+    m = len(owner)
+    order = np.argsort(owner, kind="stable").astype(np.int32)            # vertices grouped by owner, original order inside
+    counts = np.bincount(owner, minlength=int(owner.max()) + 1 if m else 1)
+    r0 = int(counts[:rank].sum())
+    r1 = r0 + int(counts[rank]) if rank < len(counts) else r0
+    ident = np.arange(m, dtype=np.int32)
+    blk = H.permuted_block(row_ptr, col_idx, values, order, ident, r0, r1)
+    return blk, order[r0:r1].copy()
+
+
+def split_by_owner(blk, owner, rank):
+    """(local, remote): the block's entries whose column is owned by `rank` / by a peer, as two CSRs over the same rows
+    (entry order inside a row kept) — y = A_loc x can start before the halo has arrived, y += A_rem x follows it."""
+    lm = blk["m"]
+    rows = np.repeat(np.arange(lm, dtype=np.int32), np.diff(blk["row_ptr"]))
+    loc = owner[blk["col_idx"]] == rank
+    out = []
+    for mask in (loc, ~loc):
+        rp = np.zeros(lm + 1, np.int64)
+        np.cumsum(np.bincount(rows[mask], minlength=lm), out=rp[1:])
+        out.append(dict(m=lm, nnz=int(rp[lm]), row_ptr=rp.astype(np.int32), col_idx=np.ascontiguousarray(blk["col_idx"][mask]),
+                        values=np.ascontiguousarray(blk["values"][mask])))
+    return out[0], out[1]
+
+
+class PackedExchange:
+    """Halo exchange for the original-numbering layout: every rank keeps a full-length x in the matrix's ORIGINAL numbering
+    (so its rows keep the column patterns the single-GPU format compresses), owns the entries of its vertices and receives
+    only the entries its rows read from peers. Per step: gather the entries peers need into one packed buffer (one
+    index_select), grouped RCCL send/recv of the per-peer segments (batch_isend_irecv), scatter what arrived to its original
+    positions (one index_copy_). The index lists come from spmv_host.halo_lists — computed by every rank on its own from the
+    shared matrix and owner map, ascending on both sides, so the packed segments need no header."""
+
+    def __init__(self, dist, torch, x_full, send, recv, rank, world):
+        self.dist, self.torch, self.x_full, self.rank, self.world = dist, torch, x_full, rank, world
+        dev = x_full.device
+        cat = lambda lists: np.concatenate([np.asarray(l, np.int64) for l in lists]) if len(lists) else np.zeros(0, np.int64)
+        self.send_idx = torch.from_numpy(cat(send)).to(dev)
+        self.recv_idx = torch.from_numpy(cat(recv)).to(dev)
+        self.sendbuf = torch.zeros(len(self.send_idx), dtype=x_full.dtype, device=dev)
+        self.recvbuf = torch.zeros(len(self.recv_idx), dtype=x_full.dtype, device=dev)
+        so = np.concatenate([[0], np.cumsum([len(l) for l in send])]).astype(np.int64)
+        ro = np.concatenate([[0], np.cumsum([len(l) for l in recv])]).astype(np.int64)
+        self.send_elems, self.recv_elems = int(so[-1]), int(ro[-1])
+        self.recv_max_from_one_peer = int(max([len(l) for l in recv] + [0]))
+        P = dist.P2POp
+        self._ops = []
+        for q in range(world):
+            if q == rank:
+                continue
+            if ro[q + 1] > ro[q]:
+                self._ops.append(P(dist.irecv, self.recvbuf[ro[q]:ro[q + 1]], q))
+        for q in range(world):
+            if q == rank:
+                continue
+            if so[q + 1] > so[q]:
+                self._ops.append(P(dist.isend, self.sendbuf[so[q]:so[q + 1]], q))
+
+    def start(self):
+        """Pack on the current stream and post the sends/receives; returns the requests for finish()."""
+        if self.send_elems:
+            self.torch.index_select(self.x_full, 0, self.send_idx, out=self.sendbuf)
+        return self.dist.batch_isend_irecv(self._ops) if self._ops else []
+
+    def finish(self, reqs):
+        for r in reqs:
+            r.wait()
+        if self.recv_elems:
+            self.x_full.index_copy_(0, self.recv_idx, self.recvbuf)
 
 
 def padded_len(offsets, align=64):

@@ -14,7 +14,7 @@ SYMBOLS = [
     "spmv_host_csr_free", "spmv_host_gen_twin", "spmv_host_gen_named", "spmv_host_gen_kkt", "spmv_host_csr_features",
     "spmv_host_gen_kkt_row_ptr", "spmv_host_gen_kkt_block", "spmv_host_remap_columns", "spmv_host_column_ranges",
     "spmv_host_bfs_order", "spmv_host_owners_from_order", "spmv_host_partition_volume", "spmv_host_partition_layout",
-    "spmv_host_permuted_block",
+    "spmv_host_permuted_block", "spmv_host_halo_lists",
 ]
 
 
@@ -225,6 +225,21 @@ def permuted_block(row_ptr, col_idx, values, perm, inv, r0, r1):
     _check(lib().spmv_host_permuted_block(_p(_i32(row_ptr)), _p(_i32(col_idx)), _p(values), C.c_long(len(perm)), _p(_i32(perm)),
                                           _p(_i32(inv)), C.c_long(r0), C.c_long(r1), C.byref(csr)))
     return _take_csr(csr)
+
+
+def halo_lists(row_ptr, col_idx, owner, parts, rank):
+    """(send, recv): per part q the ascending original vertex numbers `rank` sends to / receives from q."""
+    so = np.zeros(parts + 1, np.int64)
+    ro = np.zeros(parts + 1, np.int64)
+    sl = C.POINTER(C.c_int32)()
+    rl = C.POINTER(C.c_int32)()
+    _check(lib().spmv_host_halo_lists(_p(_i32(row_ptr)), _p(_i32(col_idx)), C.c_long(len(owner)), _p(_i32(owner)), C.c_long(parts),
+                                      C.c_long(rank), _p(so), C.byref(sl), _p(ro), C.byref(rl)))
+    s = np.ctypeslib.as_array(sl, shape=(max(int(so[-1]), 1),))[:int(so[-1])].copy()
+    r = np.ctypeslib.as_array(rl, shape=(max(int(ro[-1]), 1),))[:int(ro[-1])].copy()
+    lib().spmv_host_free(sl)
+    lib().spmv_host_free(rl)
+    return ([s[so[q]:so[q + 1]] for q in range(parts)], [r[ro[q]:ro[q + 1]] for q in range(parts)])
 
 
 FEATURES = ("avg_nnz_per_row", "std_nnz_per_row", "avg_bw_scaled", "skew", "avg_num_neighbours",

@@ -103,3 +103,56 @@ def test_row_partition_allgather_gloo(world, mode):
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) <= 1e-12
+
+
+def _worker_packed(rank, world, port, q):
+    """Original-numbering layout: full-length x on every rank, packed halo exchange (spmv_dist.PackedExchange)."""
+    for p in (os.path.join(ROOT, "spmv-research_amd", "python"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    import oracle as orc
+    import spmv_dist as D
+    import spmv_host as H
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A = H.gen_kkt(9)
+        m = A["m"]
+        x = np.random.default_rng(14).uniform(-1, 1, m)
+        part = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, world, "graph")
+        owner = part.owner()
+        send, recv = H.halo_lists(A["row_ptr"], A["col_idx"], owner, world, rank)
+        blk, rows = D.original_block(A["row_ptr"], A["col_idx"], A["values"], owner, rank)
+        loc, rem = D.split_by_owner(blk, owner, rank)
+        x_full = torch.full((m,), float("nan"), dtype=torch.float64)         # NaN: an entry that never arrives poisons y
+        x_full[torch.from_numpy(rows)] = torch.from_numpy(x[rows])
+        ex = D.PackedExchange(dist, torch, x_full, send, recv, rank, world)
+        assert ex.recv_elems == int(part.volume[rank])
+        for it in range(2):                                                  # twice: the cached op list is reusable
+            reqs = ex.start()
+            y_loc = orc.csr_spmv(loc["row_ptr"], loc["col_idx"], loc["values"], np.nan_to_num(x_full.numpy()))   # owned columns only
+            ex.finish(reqs)
+            xs = x_full.numpy()
+            assert not np.isnan(xs[blk["col_idx"]]).any()
+            y = y_loc + orc.csr_spmv(rem["row_ptr"], rem["col_idx"], rem["values"], np.nan_to_num(xs))
+        y_ref = orc.csr_spmv(A["row_ptr"], A["col_idx"], A["values"], x)[rows]
+        absrow = orc.csr_spmv(A["row_ptr"], A["col_idx"], np.abs(A["values"]), np.abs(x))[rows]
+        err = torch.tensor([float(np.max(np.abs(y - y_ref) / absrow))], dtype=torch.float64)
+        dist.all_reduce(err, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            q.put(float(err.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_packed_halo_exchange_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_packed, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) <= 1e-12

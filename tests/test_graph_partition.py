@@ -102,3 +102,39 @@ def test_balance_of_the_graph_partition():
     part = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, 8, "graph")
     per = np.array([D.partition_block(A["row_ptr"], A["col_idx"], A["values"], part, r)["nnz"] for r in range(8)])
     assert per.sum() == nnz and per.max() <= 1.1 * nnz / 8
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_halo_lists_and_original_numbering_blocks(world):
+    """Original-numbering layout: send list of p towards q == receive list of q from p (both ascending, so packed buffers
+    need no header); a rank's rows + its own x entries + what it receives reproduce its rows of y = A x exactly as
+    local + remote; the received count is the partition's volume."""
+    A = H.gen_kkt(12)
+    m = A["m"]
+    part = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, world, "graph")
+    owner = part.owner()
+    np.testing.assert_array_equal(np.bincount(owner, minlength=world), np.diff(part.offsets))
+    S = _csr(A)
+    x = np.random.default_rng(0).uniform(-1, 1, m)
+    y = S @ x
+    lists = [H.halo_lists(A["row_ptr"], A["col_idx"], owner, world, r) for r in range(world)]
+    for p in range(world):
+        send, recv = lists[p]
+        assert len(send[p]) == 0 and len(recv[p]) == 0
+        for q in range(world):
+            np.testing.assert_array_equal(send[q], lists[q][1][p])
+            assert np.all(np.diff(send[q]) > 0) and np.all(owner[send[q]] == p) and np.all(owner[recv[q]] == q)
+        assert part.volume[p] == sum(len(l) for l in recv)
+        blk, rows = D.original_block(A["row_ptr"], A["col_idx"], A["values"], owner, p)
+        np.testing.assert_array_equal(rows, np.flatnonzero(owner == p))
+        loc, rem = D.split_by_owner(blk, owner, p)
+        assert loc["nnz"] + rem["nnz"] == blk["nnz"] and np.all(owner[loc["col_idx"]] == p) and np.all(owner[rem["col_idx"]] != p)
+        have = np.full(m, np.nan)
+        have[rows] = x[rows]
+        for q in range(world):
+            have[recv[q]] = x[recv[q]]
+        assert not np.isnan(have[blk["col_idx"]]).any()              # everything the rows read is owned or received
+        have = np.nan_to_num(have)
+        mk = lambda b: sp.csr_matrix((b["values"], b["col_idx"], b["row_ptr"]), shape=(b["m"], m))
+        np.testing.assert_allclose(mk(loc) @ have + mk(rem) @ have, y[rows], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal((mk(blk) @ have), (S[rows] @ x))

@@ -8,7 +8,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29517 \
   bench.py --gpus 4 --backend gloo --steps 5 --warmup 2 --scale 0.02 > gpurun_out/part_gloo4_small.json 2> gpurun_out/part_gloo4_small.err \
   && tail -c 1500 gpurun_out/part_gloo4_small.json \
-  && timeout -k 10 700 python tools/partition_probe.py --worlds 2,8 --out gpurun_out/partition_probe.json > gpurun_out/partition_probe.log 2>&1 \
+  && timeout -k 10 700 python tools/partition_probe.py --worlds ${PROBE_WORLDS:-2,8} --modes ${PROBE_MODES:-rows,graph,graph-original} --out gpurun_out/partition_probe.json > gpurun_out/partition_probe.log 2>&1 \
   && grep -v "rank" gpurun_out/partition_probe.log \
   && timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29518 \
   bench.py --gpus 4 --backend gloo --steps 3 --warmup 1 > gpurun_out/part_gloo4_full.json 2> gpurun_out/part_gloo4_full.err \

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--worlds", default="2,8")
     ap.add_argument("--format", default="sell_c_sigma")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--modes", default="rows,graph,graph-original",
+                    help="rows | graph (P A P^T, padded x slices) | graph-original (same owners, x and columns in original numbering)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import torch
@@ -38,26 +40,40 @@ def main():
     s = torch.cuda.current_stream().cuda_stream
     records = []
     for world in [int(w) for w in args.worlds.split(",")]:
-        for mode in ("rows", "graph"):
+        for mode in args.modes.split(","):
             t = time.time()
-            part = D.graph_partition(A["row_ptr"], A["col_idx"], m, n, world, mode)
+            original = mode == "graph-original"
+            part = D.graph_partition(A["row_ptr"], A["col_idx"], m, n, world, "graph" if original else mode)
             t_part = time.time() - t
             padded = D.padded_len(part.offsets)
-            x = torch.from_numpy(np.random.default_rng(14).uniform(-1, 1, world * padded)).cuda()
+            owner = part.owner() if original else None
+            n_x = n if original else world * padded
+            x = torch.from_numpy(np.random.default_rng(14).uniform(-1, 1, n_x)).cuda()
             per_rank = []
             for r in range(world):
-                blk = D.partition_block(A["row_ptr"], A["col_idx"], A["values"], part, r)
-                D.to_padded_columns(blk["col_idx"], part.offsets, padded)
-                rg = D.needed_subranges(blk["col_idx"], padded, world)
-                recv = int(sum((rg[q, :, 1] - rg[q, :, 0]).sum() for q in range(world) if q != r))
-                recv_max_peer = int(max((rg[q, :, 1] - rg[q, :, 0]).sum() for q in range(world) if q != r))
+                if original:
+                    blk, _rows = D.original_block(A["row_ptr"], A["col_idx"], A["values"], owner, r)
+                    _send, _recv = H.halo_lists(A["row_ptr"], A["col_idx"], owner, world, r)
+                    recv = int(sum(len(l) for l in _recv))
+                    recv_max_peer = int(max(len(l) for l in _recv))
+                    pair = D.split_by_owner(blk, owner, r)
+                else:
+                    blk = D.partition_block(A["row_ptr"], A["col_idx"], A["values"], part, r)
+                    D.to_padded_columns(blk["col_idx"], part.offsets, padded)
+                    rg = D.needed_subranges(blk["col_idx"], padded, world)
+                    recv = int(sum((rg[q, :, 1] - rg[q, :, 0]).sum() for q in range(world) if q != r))
+                    recv_max_peer = int(max((rg[q, :, 1] - rg[q, :, 0]).sum() for q in range(world) if q != r))
                 c0, c1 = r * padded, r * padded + blk["m"]
                 y = torch.zeros(blk["m"] + 64, dtype=torch.float64, device="cuda")
                 ms = []
                 fp = 0.0
                 for fm in (1, 2):
-                    M = E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], blk["m"], world * padded, args.format, np.float64,
-                                 col_begin=c0, col_end=c1, col_filter_mode=fm)
+                    if original:
+                        b = pair[fm - 1]
+                        M = E.Matrix(b["row_ptr"], b["col_idx"], b["values"], blk["m"], n_x, args.format, np.float64)
+                    else:
+                        M = E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], blk["m"], n_x, args.format, np.float64,
+                                     col_begin=c0, col_end=c1, col_filter_mode=fm)
                     M.time_device(x.data_ptr(), y.data_ptr(), 5, s)
                     ms.append(float(np.median([M.time_device(x.data_ptr(), y.data_ptr(), args.iters, s) for _ in range(3)])))
                     fp += M.mem_footprint if hasattr(M, "mem_footprint") else 0.0
@@ -69,7 +85,7 @@ def main():
                 print(f"[probe] world {world} {mode} rank {r}: rows {blk['m']} nnz {blk['nnz']} recv {recv} local {ms[0]*1e3:.1f} us remote {ms[1]*1e3:.1f} us", flush=True)
                 del blk, y
             step = max(max(p["local_ms"], p["exchange_model_ms"]) + p["remote_ms"] for p in per_rank)
-            rec = dict(workload=args.workload, scale=args.scale, world=world, partition=part.kind, partition_seconds=round(t_part, 2),
+            rec = dict(workload=args.workload, scale=args.scale, world=world, partition=mode, partition_seconds=round(t_part, 2),
                        padded_slice=padded, model_step_ms=round(step, 4), model_link_gbps=LINK_GBPS,
                        model="max over ranks of max(local kernel, largest single-peer receive / link rate) + remote kernel",
                        ranks=per_rank)
