@@ -239,11 +239,15 @@ def main():
                     packed.finish(packed.start())
                     torch.cuda.synchronize()
                     want = np.concatenate([x_host[l] for l in recv]) if packed.recv_elems else np.zeros(0, np_dtype)
-                    if not np.array_equal(x_orig[packed.recv_idx].cpu().numpy(), want):
+                    got = x_orig[packed.recv_idx].cpu().numpy()
+                    if not np.array_equal(got, want):
                         ok = 0
+                        print(f"[bench] rank {rank}: packed halo exchange delivered {int((got != want).sum())} wrong entries of "
+                              f"{len(want)}", file=sys.stderr)
                 except Exception as e:
                     ok = 0
                     partition_info["packed_exchange_error"] = repr(e)[:200]
+                    print(f"[bench] rank {rank}: packed halo exchange failed: {repr(e)[:300]}", file=sys.stderr)
                 flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) == 1:

@@ -137,6 +137,9 @@ class PackedExchange:
         ro = np.concatenate([[0], np.cumsum([len(l) for l in recv])]).astype(np.int64)
         self.send_elems, self.recv_elems = int(so[-1]), int(ro[-1])
         self.recv_max_from_one_peer = int(max([len(l) for l in recv] + [0]))
+        # RCCL orders its transfers after the work already queued on the current stream; the gloo rehearsal backend reads a
+        # device send buffer without looking at the stream, so there the pack has to be finished first
+        self.sync_after_pack = x_full.is_cuda and dist.get_backend() != "nccl"
         P = dist.P2POp
         self._ops = []
         for q in range(world):
@@ -154,6 +157,8 @@ class PackedExchange:
         """Pack on the current stream and post the sends/receives; returns the requests for finish()."""
         if self.send_elems:
             self.torch.index_select(self.x_full, 0, self.send_idx, out=self.sendbuf)
+            if self.sync_after_pack:
+                self.torch.cuda.synchronize()
         return self.dist.batch_isend_irecv(self._ops) if self._ops else []
 
     def finish(self, reqs):
