@@ -852,34 +852,54 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 					const int NG = 1024 / G;
 					long nb = 256L * (o.merge_items > 0 ? o.merge_items : std::max(1L, std::min(8L, lnnz / (256L * 24576L))));
 					nb = std::max(1L, std::min(nb, (lm + 2 * NG - 1) / (2 * NG)));
-					std::vector<int> b_row((size_t) nb + 1), b_lo((size_t) nb, 0), b_w((size_t) nb, 0);
-					std::vector<long> b_nnz((size_t) nb + 1);
-					for (long b = 0; b <= nb; b++)
-					{
-						const long target = (long) ((double) lnnz * b / nb);
-						long r = std::lower_bound(rp, rp + lm + 1, (int) std::min<long>(target, 0x7fffffffL)) - rp;
-						b_row[b] = (int) (b == 0 ? 0 : b == nb ? lm : std::min<long>(std::max<long>(r, b_row[b - 1]), lm));
-						b_nnz[b] = rp[b_row[b]];
-					}
+					std::vector<int> b_row, b_lo, b_w;
+					std::vector<long> b_nnz;
 					const long budget = csr_window_lds_budget() / (long) A->vbytes;
 					long with_window = 0;
 					int max_w = 0;
-					#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4) reduction(+ : with_window) reduction(max : max_w)
-					for (long b = 0; b < nb; b++)
+					for (int attempt = 0; attempt < 2; attempt++)
 					{
-						int lo = 0x7fffffff, hi = -1;
-						for (long j = rp[b_row[b]]; j < rp[b_row[b + 1]]; j++)
+						b_row.assign((size_t) nb + 1, 0);
+						b_lo.assign((size_t) nb, 0);
+						b_w.assign((size_t) nb, 0);
+						b_nnz.assign((size_t) nb + 1, 0);
+						for (long b = 0; b <= nb; b++)
 						{
-							lo = std::min(lo, ci[j]);
-							hi = std::max(hi, ci[j]);
+							const long target = (long) ((double) lnnz * b / nb);
+							long r = std::lower_bound(rp, rp + lm + 1, (int) std::min<long>(target, 0x7fffffffL)) - rp;
+							b_row[b] = (int) (b == 0 ? 0 : b == nb ? lm : std::min<long>(std::max<long>(r, b_row[b - 1]), lm));
+							b_nnz[b] = rp[b_row[b]];
 						}
-						if (hi >= 0 && (long) hi - lo + 1 <= budget)
+						with_window = 0;
+						max_w = 0;
+						#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4) reduction(+ : with_window) reduction(max : max_w)
+						for (long b = 0; b < nb; b++)
 						{
-							b_lo[b] = lo;
-							b_w[b] = hi - lo + 1;
-							with_window++;
-							max_w = std::max(max_w, b_w[b]);
+							int lo = 0x7fffffff, hi = -1;
+							for (long j = rp[b_row[b]]; j < rp[b_row[b + 1]]; j++)
+							{
+								lo = std::min(lo, ci[j]);
+								hi = std::max(hi, ci[j]);
+							}
+							if (hi >= 0 && (long) hi - lo + 1 <= budget)
+							{
+								b_lo[b] = lo;
+								b_w[b] = hi - lo + 1;
+								with_window++;
+								max_w = std::max(max_w, b_w[b]);
+							}
 						}
+						// One 1024-thread block per CU is half the CU's wave slots. When the window is set by the matrix's
+						// bandwidth rather than by the block (it does not shrink with the block) and two of them fit the CU's
+						// 160 KiB of LDS, twice the blocks put two on every CU: pwtk twin fp32 (54 KiB windows) 17.8 -> 16.2 us.
+						// Small blocks lose more than they gain (cant twin: 7.8 k non-zeros per block, 9.9 -> 13.0 us).
+						if (attempt == 0 && o.merge_items == 0 && nb == 256 && with_window == nb && (long) max_w * A->vbytes > 16 * 1024 &&
+						    2L * (((long) max_w * A->vbytes + 15) / 16 * 16) <= 144L * 1024 && lnnz / 512 >= 20000 && lm >= 2L * 512 * NG)
+						{
+							nb = 512;
+							continue;
+						}
+						break;
 					}
 					// 16-bit window-relative indices need every non-empty block to have a window of at most 65 536 columns
 					bool eligible16 = max_w <= 65536 && lnnz > 0;
