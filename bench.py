@@ -252,10 +252,13 @@ def main():
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) == 1:
                     layout = "original"
-                    blk, mine2 = D.original_block(row_ptr_g, A["col_idx"], A["values"], owner, rank)
-                    assert np.array_equal(mine, mine2)
+                    # the rank's rows, interior rows first (all columns owned: computed while the halo is in flight), boundary
+                    # rows after them (computed when it has arrived); every row whole, in the matrix's own entry order
+                    blk = D.interior_boundary_blocks(row_ptr_g, A["col_idx"], A["values"], owner, rank)
+                    assert np.array_equal(np.sort(blk["rows"]), mine)
+                    partition_info["interior_rows"], partition_info["boundary_rows"] = int(blk["split"]), int(blk["m"] - blk["split"])
                     if args.overlap:
-                        blk_pair = D.split_by_owner(blk, owner, rank)
+                        blk_pair = (blk["interior"], blk["boundary"])
                 elif args.layout == "original":
                     raise SystemExit("--layout original: the packed halo exchange did not validate on every rank")
                 else:
@@ -281,7 +284,10 @@ def main():
     if world == 1:
         mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype, **opts)]
     elif layout == "original" and args.overlap:
-        mats = [E.Matrix(b["row_ptr"], b["col_idx"], b["values"], lm, n_x, fmt, np_dtype, **opts) for b in blk_pair]
+        # (handle, first row of y it writes, phase: 0 = while the halo is in flight, 1 = after it has arrived)
+        launches = [(E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n_x, fmt, np_dtype, **opts), first, phase)
+                    for b, first, phase in ((blk_pair[0], 0, 0), (blk_pair[1], blk["split"], 1)) if b["m"] > 0]
+        mats = [l[0] for l in launches]
         blk_pair = None
     elif args.overlap:
         c0, c1 = rank * padded, rank * padded + (r1 - r0)
@@ -319,9 +325,16 @@ def main():
         if layout == "original":
             reqs = packed.start()                               # pack + grouped send/recv of the halo
             if args.overlap:
-                mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)      # columns this rank owns, meanwhile
-            packed.finish(reqs)                                 # wait + scatter to the original positions
-            mats[-1].spmv_device(x_full.data_ptr(), y.data_ptr(), 1 if args.overlap else 0, sp)
+                for M, first, phase in launches:
+                    if phase == 0:                              # interior rows: every column is owned by this rank
+                        M.spmv_device(x_full.data_ptr(), y.data_ptr() + first * vbytes, 0, sp)
+                packed.finish(reqs)                             # wait + scatter to the original positions
+                for M, first, phase in launches:
+                    if phase == 1:                              # boundary rows
+                        M.spmv_device(x_full.data_ptr(), y.data_ptr() + first * vbytes, 0, sp)
+            else:
+                packed.finish(reqs)
+                mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
             return
         if use_p2p:
             reqs = exch.start()
@@ -431,6 +444,10 @@ def main():
                 r.wait()
 
         def kernels_only():
+            if layout == "original" and args.overlap:
+                for M, first, _phase in launches:
+                    M.spmv_device(x_full.data_ptr(), y.data_ptr() + first * vbytes, 0, sp)
+                return
             mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
             if args.overlap:
                 mats[1].spmv_device(x_full.data_ptr(), y.data_ptr(), 1, sp)
@@ -516,7 +533,7 @@ def main():
                    "parallelism": "single GPU" if world == 1 else
                    f"row-partitioned x{world} ({'row blocks of A' if partition_info['kind'] == 'rows' else 'breadth-first slabs of the matrix graph, x in original numbering' if layout == 'original' else 'row blocks of P A P^T, P = breadth-first slabs'}), "
                    f"RCCL {'packed halo send/recv' if layout == 'original' else 'send/recv of the needed x ranges' if use_p2p else 'allgather(x)'} "
-                   f"{'overlapped with local columns' if args.overlap else 'then SpMV'}"},
+                   f"{('overlapped with the interior rows' if layout == 'original' else 'overlapped with local columns') if args.overlap else 'then SpMV'}"},
         "hbm_gbps_algorithmic": round(B_alg / (ms_per_step * 1e-3) / 1e9, 2),
         "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 2),
         "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -102,6 +102,34 @@ def original_block(row_ptr, col_idx, values, owner, rank):
     return blk, order[r0:r1].copy()
 
 
+def interior_boundary_blocks(row_ptr, col_idx, values, owner, rank):
+    """The rank's rows for the original-numbering layout, INTERIOR rows first (every column owned by the rank: they can be
+    computed while the halo is in flight), then the BOUNDARY rows (at least one column owned by a peer: computed once the
+    halo has arrived) — both groups in ascending original order with original column indices, each row whole, so a row is
+    summed in the matrix's own entry order whatever the number of GPUs. Returns dict(rows = original row numbers in the
+    order of the rank's y, split = number of interior rows, interior = CSR, boundary = CSR)."""
+    blk, rows = original_block(row_ptr, col_idx, values, owner, rank)
+    lm = blk["m"]
+    remote = (owner[blk["col_idx"]] != rank).astype(np.int64)
+    per_row = np.zeros(lm, np.int64)
+    nz = np.flatnonzero(np.diff(blk["row_ptr"]) > 0)
+    if len(nz):
+        per_row[nz] = np.add.reduceat(remote, blk["row_ptr"][:-1][nz])
+    del remote
+    order = np.argsort(per_row > 0, kind="stable")                        # interior (False) first, ascending inside a group
+    split = int((per_row == 0).sum())
+    if split < lm and not np.array_equal(order, np.arange(lm)):
+        rows = rows[order]
+        blk = H.permuted_block(row_ptr, col_idx, values, np.ascontiguousarray(rows, np.int32), np.arange(len(owner), dtype=np.int32), 0, lm)
+    rp = blk["row_ptr"]
+    cut = int(rp[split])
+    interior = dict(m=split, nnz=cut, row_ptr=rp[:split + 1].copy(), col_idx=blk["col_idx"][:cut], values=blk["values"][:cut])
+    boundary = dict(m=lm - split, nnz=int(rp[lm]) - cut, row_ptr=(rp[split:] - cut).astype(np.int32), col_idx=blk["col_idx"][cut:],
+                    values=blk["values"][cut:])
+    return dict(rows=rows, split=split, interior=interior, boundary=boundary, m=lm, nnz=int(rp[lm]), row_ptr=rp,
+                col_idx=blk["col_idx"], values=blk["values"])
+
+
 def split_by_owner(blk, owner, rank):
     """(local, remote): the block's entries whose column is owned by `rank` / by a peer, as two CSRs over the same rows
     (entry order inside a row kept) — y = A_loc x can start before the halo has arrived, y += A_rem x follows it."""

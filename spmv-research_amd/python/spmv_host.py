@@ -222,7 +222,8 @@ def permuted_block(row_ptr, col_idx, values, perm, inv, r0, r1):
     """Rows [r0,r1) of P A P^T as a local CSR (columns in the new numbering, ascending)."""
     values = np.ascontiguousarray(values, np.float64)
     csr = _Csr()
-    _check(lib().spmv_host_permuted_block(_p(_i32(row_ptr)), _p(_i32(col_idx)), _p(values), C.c_long(len(perm)), _p(_i32(perm)),
+    assert 0 <= r0 <= r1 <= len(perm)                # perm may be just a row list (then inv still spans every column)
+    _check(lib().spmv_host_permuted_block(_p(_i32(row_ptr)), _p(_i32(col_idx)), _p(values), C.c_long(len(inv)), _p(_i32(perm)),
                                           _p(_i32(inv)), C.c_long(r0), C.c_long(r1), C.byref(csr)))
     return _take_csr(csr)
 

@@ -92,3 +92,44 @@ def test_padded_layout_rank_kernels_match_oracle(oracle, world, fmt):
         Ml.close(); Mr.close()
         err = np.abs(y - y_ref[r0:r1]) / np.maximum(absrow[r0:r1], 1e-300)
         assert err.max() <= 1e-12, (r, err.max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("fmt", FORMATS)
+@pytest.mark.parametrize("name,world", [("kkt", 2), ("kkt", 8), ("scircuit", 4)])
+def test_interior_and_boundary_row_handles_match_the_undivided_matrix(oracle, name, world, fmt, dtype):
+    """bench.py's original-numbering layout: an interior-row handle (runs while the halo is in flight: x holds NaN for
+    everything not owned) and a boundary-row handle writing behind it in the same y. Rows are whole and in the matrix's own
+    entry order, so y must equal the SAME kernel's result on the undivided matrix to the format's tolerance and the oracle's
+    to 1e-12 / 1e-5."""
+    import spmv_mi355x as eng
+    A = _matrix(name)
+    m = A["m"]
+    part = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, world, "graph")
+    owner = part.owner()
+    x = np.random.default_rng(5).uniform(-1, 1, m).astype(dtype)
+    vals = A["values"].astype(dtype)
+    y_ref = oracle.csr_spmv(A["row_ptr"], A["col_idx"], vals, x)
+    absrow = oracle.csr_spmv(A["row_ptr"], A["col_idx"], np.abs(vals).astype(np.float64), np.abs(x).astype(np.float64))
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    for r in range(world):
+        B = D.interior_boundary_blocks(A["row_ptr"], A["col_idx"], A["values"], owner, r)
+        rows, t = B["rows"], B["split"]
+        _send, recv = H.halo_lists(A["row_ptr"], A["col_idx"], owner, world, r)
+        xr = np.full(m, np.nan, dtype)
+        xr[rows] = x[rows]
+        y = np.zeros(B["m"], np.float64)
+        if t > 0:
+            Mi = eng.Matrix(B["interior"]["row_ptr"], B["interior"]["col_idx"], B["interior"]["values"], t, m, fmt, dtype)
+            y[:t] = Mi.spmv(np.where(np.isnan(xr), 0, xr).astype(dtype))
+            Mi.close()
+            assert np.all(owner[B["interior"]["col_idx"]] == r)
+        for q in range(world):
+            xr[recv[q]] = x[recv[q]]
+        assert not np.isnan(xr[B["col_idx"]]).any()
+        if B["m"] - t > 0:
+            Mb = eng.Matrix(B["boundary"]["row_ptr"], B["boundary"]["col_idx"], B["boundary"]["values"], B["m"] - t, m, fmt, dtype)
+            y[t:] = Mb.spmv(np.where(np.isnan(xr), 0, xr).astype(dtype))
+            Mb.close()
+        err = np.abs(y - y_ref[rows].astype(np.float64)) / np.maximum(absrow[rows], 1e-300)
+        assert err.max() <= tol, (r, err.max())

@@ -138,3 +138,31 @@ def test_halo_lists_and_original_numbering_blocks(world):
         mk = lambda b: sp.csr_matrix((b["values"], b["col_idx"], b["row_ptr"]), shape=(b["m"], m))
         np.testing.assert_allclose(mk(loc) @ have + mk(rem) @ have, y[rows], rtol=0, atol=1e-12)
         np.testing.assert_array_equal((mk(blk) @ have), (S[rows] @ x))
+
+
+@pytest.mark.parametrize("name,world", [("kkt14", 2), ("kkt14", 4), ("cant_twin", 3)])
+def test_interior_rows_first_then_boundary_rows(name, world):
+    """What bench.py builds for the original-numbering layout: interior rows (every column owned) first, boundary rows after
+    them, both ascending, every row WHOLE and in the matrix's own entry order — so each y entry is bit-identical to the same
+    row of the undivided matrix summed the same way."""
+    A = H.gen_kkt(14) if name == "kkt14" else H.gen_named("cant", 0.05)
+    m = A["m"]
+    part = D.graph_partition(A["row_ptr"], A["col_idx"], m, m, world, "graph")
+    owner = part.owner()
+    S = _csr(A)
+    for r in range(world):
+        B = D.interior_boundary_blocks(A["row_ptr"], A["col_idx"], A["values"], owner, r)
+        rows, t = B["rows"], B["split"]
+        np.testing.assert_array_equal(np.sort(rows), np.flatnonzero(owner == r))
+        assert np.all(np.diff(rows[:t]) > 0) and np.all(np.diff(rows[t:]) > 0)
+        I, Bd = B["interior"], B["boundary"]
+        assert I["m"] == t and Bd["m"] == B["m"] - t and I["nnz"] + Bd["nnz"] == B["nnz"]
+        assert np.all(owner[I["col_idx"]] == r)
+        if Bd["m"]:
+            remote = (owner[Bd["col_idx"]] != r).astype(np.int64)
+            assert np.all(np.diff(Bd["row_ptr"]) > 0) and np.all(np.add.reduceat(remote, Bd["row_ptr"][:-1]) > 0)
+        for blk, rr in ((I, rows[:t]), (Bd, rows[t:]), (B, rows)):
+            want = S[rr]
+            np.testing.assert_array_equal(blk["row_ptr"], want.indptr)
+            np.testing.assert_array_equal(blk["col_idx"], want.indices)
+            np.testing.assert_array_equal(blk["values"], want.data)

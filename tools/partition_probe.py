@@ -42,7 +42,8 @@ def main():
     for world in [int(w) for w in args.worlds.split(",")]:
         for mode in args.modes.split(","):
             t = time.time()
-            original = mode == "graph-original"
+            original = mode in ("graph-original", "graph-original-rows")
+            whole_rows = mode == "graph-original-rows"            # interior rows / boundary rows instead of local / remote columns
             part = D.graph_partition(A["row_ptr"], A["col_idx"], m, n, world, "graph" if original else mode)
             t_part = time.time() - t
             padded = D.padded_len(part.offsets)
@@ -52,11 +53,15 @@ def main():
             per_rank = []
             for r in range(world):
                 if original:
-                    blk, _rows = D.original_block(A["row_ptr"], A["col_idx"], A["values"], owner, r)
                     _send, _recv = H.halo_lists(A["row_ptr"], A["col_idx"], owner, world, r)
                     recv = int(sum(len(l) for l in _recv))
                     recv_max_peer = int(max(len(l) for l in _recv))
-                    pair = D.split_by_owner(blk, owner, r)
+                    if whole_rows:
+                        blk = D.interior_boundary_blocks(A["row_ptr"], A["col_idx"], A["values"], owner, r)
+                        pair = (blk["interior"], blk["boundary"])
+                    else:
+                        blk, _rows = D.original_block(A["row_ptr"], A["col_idx"], A["values"], owner, r)
+                        pair = D.split_by_owner(blk, owner, r)
                 else:
                     blk = D.partition_block(A["row_ptr"], A["col_idx"], A["values"], part, r)
                     D.to_padded_columns(blk["col_idx"], part.offsets, padded)
@@ -70,7 +75,7 @@ def main():
                 for fm in (1, 2):
                     if original:
                         b = pair[fm - 1]
-                        M = E.Matrix(b["row_ptr"], b["col_idx"], b["values"], blk["m"], n_x, args.format, np.float64)
+                        M = E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n_x, args.format, np.float64)
                     else:
                         M = E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], blk["m"], n_x, args.format, np.float64,
                                      col_begin=c0, col_end=c1, col_filter_mode=fm)
