@@ -68,6 +68,8 @@ def parse():
                          "numbering (rows keep the column patterns the format compresses) and the halo moves by pack -> send/recv -> "
                          "scatter; 'padded' = P A P^T with x as padded slices exchanged in place; 'auto' = original when its "
                          "exchange validates on every rank")
+    ap.add_argument("--halo", default="auto", choices=["auto", "alltoall", "p2p"],
+                    help="original layout: how the packed halo segments move (auto = all_to_all_single if it validates, else p2p)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -229,27 +231,35 @@ def main():
             if part.kind == "graph" and args.layout != "padded":
                 # original-numbering layout: validate its exchange BEFORE anything is built on it; all ranks take the same branch
                 owner = part.owner()
-                ok = 1
-                try:
-                    send, recv = H.halo_lists(row_ptr_g, A["col_idx"], owner, world, rank)
-                    mine = np.flatnonzero(owner == rank)
-                    x_orig = torch.zeros(n, dtype=t_dtype, device="cuda")
-                    x_orig[torch.from_numpy(mine).cuda()] = torch.from_numpy(x_host[mine]).cuda()
-                    packed = D.PackedExchange(dist, torch, x_orig, send, recv, rank, world)
-                    packed.finish(packed.start())
-                    torch.cuda.synchronize()
-                    want = np.concatenate([x_host[l] for l in recv]) if packed.recv_elems else np.zeros(0, np_dtype)
-                    got = x_orig[packed.recv_idx].cpu().numpy()
-                    if not np.array_equal(got, want):
+                send, recv = H.halo_lists(row_ptr_g, A["col_idx"], owner, world, rank)
+                mine = np.flatnonzero(owner == rank)
+                mine_dev = torch.from_numpy(mine).cuda()
+                x_orig = torch.zeros(n, dtype=t_dtype, device="cuda")
+                want = np.concatenate([x_host[l] for l in recv]) if sum(len(l) for l in recv) else np.zeros(0, np_dtype)
+                flag = None
+                # one all_to_all_single per step if the backend delivers it correctly, else grouped isend/irecv
+                for xmode in (("alltoall", "p2p") if args.halo == "auto" else (args.halo,)):
+                    ok = 1
+                    try:
+                        x_orig.zero_()
+                        x_orig[mine_dev] = torch.from_numpy(x_host[mine]).cuda()
+                        packed = D.PackedExchange(dist, torch, x_orig, send, recv, rank, world, xmode)
+                        packed.finish(packed.start())
+                        torch.cuda.synchronize()
+                        got = x_orig[packed.recv_idx].cpu().numpy()
+                        if not np.array_equal(got, want):
+                            ok = 0
+                            print(f"[bench] rank {rank}: packed halo exchange ({xmode}) delivered {int((got != want).sum())} wrong "
+                                  f"entries of {len(want)}", file=sys.stderr)
+                    except Exception as e:
                         ok = 0
-                        print(f"[bench] rank {rank}: packed halo exchange delivered {int((got != want).sum())} wrong entries of "
-                              f"{len(want)}", file=sys.stderr)
-                except Exception as e:
-                    ok = 0
-                    partition_info["packed_exchange_error"] = repr(e)[:200]
-                    print(f"[bench] rank {rank}: packed halo exchange failed: {repr(e)[:300]}", file=sys.stderr)
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                        partition_info["packed_exchange_error_" + xmode] = repr(e)[:200]
+                        print(f"[bench] rank {rank}: packed halo exchange ({xmode}) failed: {repr(e)[:300]}", file=sys.stderr)
+                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if int(flag.item()) == 1:
+                        break
+                del mine_dev
                 if int(flag.item()) == 1:
                     layout = "original"
                     # the rank's rows, interior rows first (all columns owned: computed while the halo is in flight), boundary
@@ -357,7 +367,7 @@ def main():
 
     exchange_info = None
     if world > 1 and layout == "original":
-        exchange_info = {"chosen": "packed halo p2p", "recv_x_entries": packed.recv_elems, "send_x_entries": packed.send_elems,
+        exchange_info = {"chosen": "packed halo " + packed.mode, "recv_x_entries": packed.recv_elems, "send_x_entries": packed.send_elems,
                          "recv_max_from_one_peer": packed.recv_max_from_one_peer}
     if world > 1 and layout == "padded":
         # one untimed exchange, checked: every rank must end up with the same padded x. If the in-place form (send buffer
@@ -532,7 +542,7 @@ def main():
                    "format": mats[0].format_name, "rows": int(m), "cols": int(n), "nnz": int(nnz_total),
                    "parallelism": "single GPU" if world == 1 else
                    f"row-partitioned x{world} ({'row blocks of A' if partition_info['kind'] == 'rows' else 'breadth-first slabs of the matrix graph, x in original numbering' if layout == 'original' else 'row blocks of P A P^T, P = breadth-first slabs'}), "
-                   f"RCCL {'packed halo send/recv' if layout == 'original' else 'send/recv of the needed x ranges' if use_p2p else 'allgather(x)'} "
+                   f"RCCL {'packed halo ' + ('all_to_all' if packed.mode == 'alltoall' else 'send/recv') if layout == 'original' else 'send/recv of the needed x ranges' if use_p2p else 'allgather(x)'} "
                    f"{('overlapped with the interior rows' if layout == 'original' else 'overlapped with local columns') if args.overlap else 'then SpMV'}"},
         "hbm_gbps_algorithmic": round(B_alg / (ms_per_step * 1e-3) / 1e9, 2),
         "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 2),

@@ -153,7 +153,12 @@ class PackedExchange:
     positions (one index_copy_). The index lists come from spmv_host.halo_lists — computed by every rank on its own from the
     shared matrix and owner map, ascending on both sides, so the packed segments need no header."""
 
-    def __init__(self, dist, torch, x_full, send, recv, rank, world):
+    def __init__(self, dist, torch, x_full, send, recv, rank, world, mode="p2p"):
+        """mode "p2p": batch_isend_irecv of the per-peer segments; "alltoall": ONE all_to_all_single with the segment lengths
+        as split sizes — the same transfers (RCCL runs it as one grouped send/recv) for a fraction of the host time per
+        step, which matters when a step is < 200 us of GPU time."""
+        assert mode in ("p2p", "alltoall")
+        self.mode = mode
         self.dist, self.torch, self.x_full, self.rank, self.world = dist, torch, x_full, rank, world
         dev = x_full.device
         cat = lambda lists: np.concatenate([np.asarray(l, np.int64) for l in lists]) if len(lists) else np.zeros(0, np.int64)
@@ -164,6 +169,8 @@ class PackedExchange:
         so = np.concatenate([[0], np.cumsum([len(l) for l in send])]).astype(np.int64)
         ro = np.concatenate([[0], np.cumsum([len(l) for l in recv])]).astype(np.int64)
         self.send_elems, self.recv_elems = int(so[-1]), int(ro[-1])
+        self.send_splits = [int(so[q + 1] - so[q]) for q in range(world)]
+        self.recv_splits = [int(ro[q + 1] - ro[q]) for q in range(world)]
         self.recv_max_from_one_peer = int(max([len(l) for l in recv] + [0]))
         # RCCL orders its transfers after the work already queued on the current stream; the gloo rehearsal backend reads a
         # device send buffer without looking at the stream, so there the pack has to be finished first
@@ -187,6 +194,8 @@ class PackedExchange:
             self.torch.index_select(self.x_full, 0, self.send_idx, out=self.sendbuf)
             if self.sync_after_pack:
                 self.torch.cuda.synchronize()
+        if self.mode == "alltoall":
+            return [self.dist.all_to_all_single(self.recvbuf, self.sendbuf, self.recv_splits, self.send_splits, async_op=True)]
         return self.dist.batch_isend_irecv(self._ops) if self._ops else []
 
     def finish(self, reqs):

@@ -105,7 +105,7 @@ def test_row_partition_allgather_gloo(world, mode):
     assert q.get(timeout=5) <= 1e-12
 
 
-def _worker_packed(rank, world, port, q):
+def _worker_packed(rank, world, port, q, mode="p2p"):
     """Original-numbering layout: full-length x on every rank, packed halo exchange (spmv_dist.PackedExchange)."""
     for p in (os.path.join(ROOT, "spmv-research_amd", "python"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
@@ -125,7 +125,7 @@ def _worker_packed(rank, world, port, q):
         rows, inner, outer = blk["rows"], blk["interior"], blk["boundary"]
         x_full = torch.full((m,), float("nan"), dtype=torch.float64)         # NaN: an entry that never arrives poisons y
         x_full[torch.from_numpy(rows)] = torch.from_numpy(x[rows])
-        ex = D.PackedExchange(dist, torch, x_full, send, recv, rank, world)
+        ex = D.PackedExchange(dist, torch, x_full, send, recv, rank, world, mode)
         assert ex.recv_elems == int(part.volume[rank])
         for it in range(2):                                                  # twice: the cached op list is reusable
             reqs = ex.start()
@@ -147,12 +147,13 @@ def _worker_packed(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["p2p", "alltoall"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_packed_halo_exchange_gloo(world):
+def test_packed_halo_exchange_gloo(world, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker_packed, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_packed, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
