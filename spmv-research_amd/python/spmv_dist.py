@@ -398,3 +398,95 @@ class DistributedSolver:
 
     def pbicgstab(self, b_local, max_iterations, history=True):
         return self._solve("pbicgstab", b_local, max_iterations, history)
+
+
+def diagonal_only(block, rows):
+    """CSR with just the FIRST stored diagonal entry of every row of `block` (rows[i] = the original number of local row i,
+    columns in original numbering), renumbered so that the diagonal of local row i is column i — what the solvers' Jacobi
+    extraction (solvers.hip jacobi_diagonal: first stored diagonal entry, row_offset + i) wants to see. A row without a stored
+    diagonal stays empty and is reported by the solver exactly as on one GPU."""
+    rp = np.asarray(block["row_ptr"], np.int64)
+    lm = len(rp) - 1
+    entry_row = np.repeat(np.arange(lm, dtype=np.int64), np.diff(rp))
+    hits = np.flatnonzero(np.asarray(block["col_idx"], np.int64) == np.asarray(rows, np.int64)[entry_row])
+    with_diag, first = np.unique(entry_row[hits], return_index=True)
+    drp = np.zeros(lm + 1, np.int64)
+    drp[with_diag + 1] = 1
+    np.cumsum(drp, out=drp)
+    return dict(m=lm, nnz=len(with_diag), row_ptr=drp.astype(np.int32), col_idx=with_diag.astype(np.int32),
+                values=np.ascontiguousarray(np.asarray(block["values"])[hits[first]]))
+
+
+class GraphDistributedSolver(DistributedSolver):
+    """The same solvers on the communication-aware partition (graph_partition) in the original-numbering layout: rank p owns
+    the vertices the partition gives it, keeps a full-length x in the matrix's original numbering, and its SpMV callback is
+    scatter(own vector -> x) + packed halo exchange (PackedExchange) overlapped with the interior rows + boundary rows. The
+    rank's vectors (b, x, the solver's work vectors) live in the order of `self.rows` (interior rows first, then boundary
+    rows): b_local = b[self.rows], and the returned x is x_global[self.rows]."""
+
+    def __init__(self, dist, torch, row_ptr, col_idx, values, part, rank, world, fmt="sell_c_sigma", dtype=np.float64,
+                 halo="alltoall", **opts):
+        import ctypes as C
+        import spmv_mi355x as E
+        self.dist, self.torch, self.E, self.C = dist, torch, E, C
+        self.rank, self.world = rank, world
+        self.dtype = np.dtype(dtype)
+        owner = part.owner()
+        n = len(owner)
+        blocks = interior_boundary_blocks(row_ptr, col_idx, values, owner, rank)
+        self.rows, self.split, self.m = blocks["rows"], blocks["split"], blocks["m"]
+        self.offsets = part.offsets
+        send, recv = H.halo_lists(row_ptr, col_idx, owner, world, rank)
+        td = torch.float64 if self.dtype == np.float64 else torch.float32
+        self.x_full = torch.zeros(n, dtype=td, device="cuda")
+        self.stage = torch.zeros(max(self.m, 1), dtype=td, device="cuda")
+        self.rows_dev = torch.from_numpy(np.asarray(self.rows, np.int64)).cuda()
+        self.exchange = PackedExchange(dist, torch, self.x_full, send, recv, rank, world, halo)
+        self.handles = [(E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n, fmt, dtype, **opts), first)
+                        for b, first in ((blocks["interior"], 0), (blocks["boundary"], self.split)) if b["m"] > 0]
+        self.M = self.handles[0][0] if self.handles else None
+        # the C side only reads the Jacobi diagonal from the CSR it is handed: give it exactly that, numbered by local row
+        self.block = diagonal_only(blocks, self.rows)
+        self.red = torch.zeros(8, dtype=torch.float64, device="cuda")
+        self.calls = dict(spmv=0, allreduce=0)
+        vb = self.dtype.itemsize
+
+        def spmv_cb(_ctx, in_ptr, out_ptr):
+            try:
+                E._check(E.lib().spmv_mi355x_copy_device_async(C.c_void_p(self.stage.data_ptr()), C.c_void_p(in_ptr),
+                                                              C.c_long(self.m * vb), None))
+                self.x_full.index_copy_(0, self.rows_dev, self.stage[:self.m])       # own entries to their original positions
+                reqs = self.exchange.start() if world > 1 else []
+                for M, first in self.handles:
+                    if first == 0 and self.split > 0:                                # interior rows while the halo is in flight
+                        M.spmv_device(self.x_full.data_ptr(), out_ptr, 0, 0)
+                if world > 1:
+                    self.exchange.finish(reqs)
+                for M, first in self.handles:
+                    if not (first == 0 and self.split > 0):                          # boundary rows
+                        M.spmv_device(self.x_full.data_ptr(), out_ptr + first * vb, 0, 0)
+                self.calls["spmv"] += 1
+                return 0
+            except Exception as e:                           # never let an exception cross the C frame
+                self.error = e
+                return 1
+
+        def allreduce_cb(_ctx, _buf, count):
+            try:
+                if world > 1:
+                    dist.all_reduce(self.red[:count])
+                self.calls["allreduce"] += 1
+                return 0
+            except Exception as e:
+                self.error = e
+                return 1
+
+        self.error = None
+        self._cbs = (E.SPMV_CB(spmv_cb), E.ALLREDUCE_CB(allreduce_cb))
+        self.ops = E.DistOps()
+        self.ops.struct_size = C.sizeof(E.DistOps)
+        self.ops.row_offset = 0                              # the diagonal-only CSR above is numbered by local row
+        self.ops.spmv = self._cbs[0]
+        self.ops.allreduce_sum = self._cbs[1]
+        self.ops.reduce_buf_dev = self.red.data_ptr()
+        self.ops.ctx = None

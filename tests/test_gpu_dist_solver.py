@@ -22,7 +22,7 @@ def _system(kind):
     return A, rhs(A)
 
 
-def _worker(rank, world, port, kind, method, iters, q):
+def _worker(rank, world, port, kind, method, iters, q, partition="rows"):
     for p in (os.path.join(ROOT, "spmv-research_amd", "python"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     import torch
@@ -33,11 +33,20 @@ def _worker(rank, world, port, kind, method, iters, q):
     try:
         torch.cuda.set_device(0)
         A, b = _system(kind)
-        off = D.row_partition(A.indptr.astype(np.int32), world)
-        blk = D.local_block(A.indptr.astype(np.int32), A.indices, A.data, off, rank)
-        S = D.DistributedSolver(dist, torch, blk, off, rank, world, fmt="csr_vector")
-        r = (S.pcg if method == "pcg" else S.pbicgstab)(b[off[rank]:off[rank + 1]], iters)
-        q.put((rank, r["x"], r["iterations"], r["history"], r["error"], r["error_best"], r["restarts"], dict(S.calls)))
+        if partition == "graph":
+            # breadth-first slabs, x in original numbering, packed halo exchange overlapped with the interior rows
+            rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+            part = D.graph_partition(rp, ci, A.shape[0], A.shape[1], world, "graph")
+            S = D.GraphDistributedSolver(dist, torch, rp, ci, A.data, part, rank, world, fmt="csr_vector")
+            r = (S.pcg if method == "pcg" else S.pbicgstab)(b[S.rows], iters)
+            rows = np.asarray(S.rows)
+        else:
+            off = D.row_partition(A.indptr.astype(np.int32), world)
+            blk = D.local_block(A.indptr.astype(np.int32), A.indices, A.data, off, rank)
+            S = D.DistributedSolver(dist, torch, blk, off, rank, world, fmt="csr_vector")
+            r = (S.pcg if method == "pcg" else S.pbicgstab)(b[off[rank]:off[rank + 1]], iters)
+            rows = np.arange(off[rank], off[rank + 1])
+        q.put((rank, r["x"], r["iterations"], r["history"], r["error"], r["error_best"], r["restarts"], dict(S.calls), rows))
         dist.barrier()
     except Exception as e:                                        # surface the failure instead of a hung join
         import traceback
@@ -46,9 +55,10 @@ def _worker(rank, world, port, kind, method, iters, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("partition", ["rows", "graph"])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("kind,method,iters", [("laplace", "pcg", 1000), ("laplace", "pbicgstab", 130), ("nonsym", "pbicgstab", 130)])
-def test_distributed_solver_matches_single_gpu(oracle, world, kind, method, iters):
+def test_distributed_solver_matches_single_gpu(oracle, world, kind, method, iters, partition):
     import spmv_mi355x as eng
     A, b = _system(kind)
     M = eng.Matrix(A.indptr, A.indices, A.data, A.shape[0], A.shape[1], "csr_vector")
@@ -57,8 +67,8 @@ def test_distributed_solver_matches_single_gpu(oracle, world, kind, method, iter
     M.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + world * 7 + (hash((kind, method)) % 50)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, method, iters, q)) for r in range(world)]
+    port = 29600 + world * 7 + (hash((kind, method, partition)) % 50)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, method, iters, q, partition)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -69,7 +79,9 @@ def test_distributed_solver_matches_single_gpu(oracle, world, kind, method, iter
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    x = np.concatenate([res[r][0] for r in range(world)])
+    x = np.zeros(A.shape[0])
+    for r in range(world):
+        x[res[r][7]] = res[r][0]                                   # rank r's slice sits at the rows it owns
     its = {res[r][1] for r in range(world)}
     assert len(its) == 1, f"ranks disagree on the iteration count: {its}"
     it = its.pop()

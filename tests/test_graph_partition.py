@@ -166,3 +166,14 @@ def test_interior_rows_first_then_boundary_rows(name, world):
             np.testing.assert_array_equal(blk["row_ptr"], want.indptr)
             np.testing.assert_array_equal(blk["col_idx"], want.indices)
             np.testing.assert_array_equal(blk["values"], want.data)
+
+
+def test_diagonal_only_keeps_the_first_stored_diagonal_entry():
+    # local rows are original rows 5, 2, 9; row 2 has its diagonal twice (first one counts), row 9 has none
+    rows = np.array([5, 2, 9])
+    blk = dict(row_ptr=np.array([0, 3, 6, 8], np.int32), col_idx=np.array([1, 5, 7, 2, 2, 4, 0, 3], np.int32),
+               values=np.array([1., 50., 3., 20., 21., 5., 6., 7.]))
+    d = D.diagonal_only(blk, rows)
+    np.testing.assert_array_equal(d["row_ptr"], [0, 1, 2, 2])
+    np.testing.assert_array_equal(d["col_idx"], [0, 1])
+    np.testing.assert_array_equal(d["values"], [50., 20.])
