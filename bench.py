@@ -533,7 +533,7 @@ def main():
     ach = B_alg_local / (kernel_ms * 1e-3) / 1e9
     ki = mats[0].kernel_info()
     result = {
-        "metric": "GFLOP/s (2*nnz/t, fp64 SpMV y=A*x); achieved HBM GB/s and % of peak in 'roofline'",
+        "metric": f"GFLOP/s (2*nnz/t, {'fp64' if dts == 'f64' else 'fp32'} SpMV y=A*x); achieved HBM GB/s and % of peak in 'roofline'",
         "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
         "scaling": "strong",            # total work (one SpMV of the whole matrix) is fixed as N grows

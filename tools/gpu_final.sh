@@ -12,7 +12,9 @@ timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 
   && timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > gpurun_out/final_smoke.log 2>&1 \
   && tail -2 gpurun_out/final_smoke.log \
   && timeout -k 10 600 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err \
-  && tail -c 1500 gpurun_out/bench_final.json
+  && tail -c 1500 gpurun_out/bench_final.json \
+  && timeout -k 10 600 python bench.py --dtype f32 --no-cpu-baseline > gpurun_out/bench_final_f32.json 2> gpurun_out/bench_final_f32.err \
+  && tail -c 900 gpurun_out/bench_final_f32.json
 echo "rc=$?"
 grep "\[bench\]" gpurun_out/part_gloo2_full.err | cut -c1-300 | head -5
 true
