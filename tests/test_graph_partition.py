@@ -177,3 +177,52 @@ def test_diagonal_only_keeps_the_first_stored_diagonal_entry():
     np.testing.assert_array_equal(d["row_ptr"], [0, 1, 2, 2])
     np.testing.assert_array_equal(d["col_idx"], [0, 1])
     np.testing.assert_array_equal(d["values"], [50., 20.])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_graphs_fuzz(seed):
+    """Random square patterns — unsymmetric, self loops, empty rows, duplicates, isolated vertices, more parts than busy
+    vertices: every piece of the partition machinery must stay consistent with scipy's permutation algebra."""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(1, 400))
+    nnz = int(rng.integers(0, 6 * m + 1))
+    R = rng.integers(0, m, nnz)
+    Cc = np.clip(R + rng.integers(-12, 13, nnz), 0, m - 1) if seed % 2 else rng.integers(0, m, nnz)
+    order = np.lexsort((Cc, R))                                   # rows ascending, columns ascending, duplicates kept
+    R, Cc = R[order], Cc[order]
+    rp = np.zeros(m + 1, np.int32)
+    np.add.at(rp, R + 1, 1)
+    rp = np.cumsum(rp).astype(np.int32)
+    ci = Cc.astype(np.int32)
+    va = rng.uniform(-1, 1, nnz)
+    world = int(rng.integers(2, 9))
+    S = sp.csr_matrix((va, ci, rp), shape=(m, m))                 # duplicates stay separate entries in .data order
+    x = rng.uniform(-1, 1, m)
+    y = np.array([np.dot(va[rp[i]:rp[i + 1]], x[ci[rp[i]:rp[i + 1]]]) for i in range(m)])
+    bo = H.bfs_order(rp, ci, m, m)
+    assert sorted(bo.tolist()) == list(range(m))
+    part = D.graph_partition(rp, ci, m, m, world, "graph")
+    owner = part.owner()
+    assert sorted(part.perm.tolist()) == list(range(m)) and np.array_equal(np.bincount(owner, minlength=world), np.diff(part.offsets))
+    vol = H.partition_volume(rp, ci, owner, world)
+    np.testing.assert_array_equal(vol, part.volume)
+    for r in range(world):
+        send, recv = H.halo_lists(rp, ci, owner, world, r)
+        assert sum(len(l) for l in recv) == vol[r]
+        B = D.interior_boundary_blocks(rp, ci, va, owner, r)
+        rows, t = B["rows"], B["split"]
+        np.testing.assert_array_equal(np.sort(rows), np.flatnonzero(owner == r))
+        have = np.full(m, np.nan)
+        have[rows] = x[rows]
+        if B["interior"]["nnz"]:
+            assert not np.isnan(have[B["interior"]["col_idx"]]).any()
+        for q in range(world):
+            have[recv[q]] = x[recv[q]]
+        got = np.array([np.dot(B["values"][B["row_ptr"][i]:B["row_ptr"][i + 1]], have[B["col_idx"][B["row_ptr"][i]:B["row_ptr"][i + 1]]])
+                        for i in range(B["m"])])
+        np.testing.assert_array_equal(got, y[rows])               # same entries in the same order: bit-identical
+        # padded P A P^T layout
+        blk = D.partition_block(rp, ci, va, part, r)
+        r0, r1 = int(part.offsets[r]), int(part.offsets[r + 1])
+        Bm = sp.csr_matrix((blk["values"], blk["col_idx"], blk["row_ptr"]), shape=(blk["m"], m))
+        np.testing.assert_allclose(Bm @ x[part.perm], y[part.perm][r0:r1], rtol=0, atol=1e-12)

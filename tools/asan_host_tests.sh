@@ -6,11 +6,11 @@ cd "$(dirname "$0")/.."
 S=spmv-research_amd
 mkdir -p /tmp/asan_lib
 g++ -O1 -g -std=c++17 -fPIC -fopenmp -march=x86-64-v3 -fsanitize=address,undefined -fno-omit-frame-pointer -shared \
-	$S/host/file_load.cpp $S/host/matrix_market.cpp $S/host/csr_convert.cpp $S/host/partition.cpp $S/host/synthetic.cpp \
+	$S/host/file_load.cpp $S/host/matrix_market.cpp $S/host/csr_convert.cpp $S/host/partition.cpp $S/host/graph_partition.cpp $S/host/synthetic.cpp \
 	$S/host/host_api.cpp -o /tmp/asan_lib/libspmv_host.so -lz -ldl
 cp $S/lib/libspmv_host.so /tmp/asan_lib/libspmv_host.so.orig
 trap 'cp /tmp/asan_lib/libspmv_host.so.orig '$S'/lib/libspmv_host.so' EXIT
 cp /tmp/asan_lib/libspmv_host.so $S/lib/libspmv_host.so
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
-	python -m pytest tests/test_host_golden.py -x -q
+	python -m pytest tests/test_host_golden.py tests/test_graph_partition.py tests/test_reader_fuzz.py -x -q
