@@ -57,6 +57,11 @@ struct spmv_mi355x_matrix {
 	int * d_coords = nullptr;
 	int * d_carry_row = nullptr;
 	void * d_carry_val = nullptr;
+	// column-blocked COO (opts.col_blocks): segments of rows, entries ordered by column block inside a segment
+	int * d_coob_seg_row = nullptr;
+	int * d_coob_seg_blk = nullptr;
+	unsigned short * d_coob_lrow = nullptr;
+	int coob_segs = 0, coob_blocks = 0, coob_lds = 0;
 	// SELL
 	int sell_c = 0;
 	long sell_sigma = 0, sell_slices = 0, sell_nnz_ext = 0;
@@ -113,7 +118,7 @@ free_all(spmv_mi355x_matrix * A)
 {
 	void * ptrs[] = {A->d_row_ptr, A->d_col, A->d_val, A->d_coords, A->d_carry_row, A->d_carry_val, A->d_slice_ptr,
 	                 A->d_row_of_sorted, A->d_rowind, A->d_x, A->d_y, A->d_sell_desc, A->d_sell_idx, A->d_win_row, A->d_win_lo,
-	                 A->d_win_w, A->d_col16};
+	                 A->d_win_w, A->d_col16, A->d_coob_seg_row, A->d_coob_seg_blk, A->d_coob_lrow};
 	for (void * p : ptrs)
 		if (p)
 			(void) hipFree(p);
@@ -285,6 +290,118 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 
 // SELL-64-sigma-delta build (layout: kernels_sell.hip). Same sigma-window sort and slice widths as build_sell with C = 64,
 // widths padded to a multiple of 4 steps; per slice the narrowest index encoding that holds every (step, lane) delta.
+// Column-blocked COO (opts.col_blocks, kernels_coo.hip): rows cut into segments of about equal non-zeros and at most
+// coo_blocked_rows_cap() rows (their y lives in LDS); inside a segment the entries are ordered by column block (stable: rows
+// ascending, columns ascending inside a block) and stored as (column, row inside the segment, value unless all equal).
+static int
+build_coo_blocked(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va, int col_blocks, const char * pf)
+{
+	const long lm = A->m, lnnz = A->nnz, n = A->n;
+	const int cap = coo_blocked_rows_cap(A->f32);
+	const long per = coo_blocked_segments_per_launch();
+	// launches: enough segments that the row cap is rarely what ends one
+	const long launches = std::max<long>(1, (long) ((double) lm / (0.75 * cap * per) + 0.999));
+	// equal shares of the entries (the workgroups must keep pace), then any share with more than `cap` rows is cut further
+	std::vector<int> seg_row(1, 0);
+	{
+		const long S0 = per * launches;
+		int prev = 0;
+		for (long sgm = 1; sgm <= S0; sgm++)
+		{
+			const long tgt = (long) ((double) lnnz * sgm / S0);
+			long r = std::lower_bound(rp, rp + lm + 1, (int) std::min<long>(tgt, 0x7fffffffL)) - rp;
+			const int end = (int) (sgm == S0 ? lm : std::min<long>(std::max<long>(r, prev), lm));
+			for (int a = prev; a < end; a += cap)
+				seg_row.push_back(std::min(a + cap, end));
+			prev = end;
+		}
+	}
+	const long S = (long) seg_row.size() - 1;
+	long W;
+	int B;
+	if (col_blocks > 0)
+	{
+		B = (int) std::min<long>(col_blocks, std::max<long>(n, 1));
+		W = std::max<long>(1, (n + B - 1) / B);
+	}
+	else
+	{
+		W = std::max<long>(1024, (1L << 20) / A->vbytes);            // ~1 MiB of x per block (an XCD's L2 is 4 MiB; flat between 24 and 96 blocks on the soc-LiveJournal1 twin)
+		B = (int) std::max<long>(1, (n + W - 1) / W);
+	}
+	B = (int) std::max<long>(1, (n + W - 1) / W);
+	if (B > 4096)
+	{
+		set_error("col_blocks: %d column blocks (limit 4096)", B);
+		return 1;
+	}
+	bool uniform = lnnz > 0;
+	double v0 = 0;
+	{
+		long differs = 0;
+		v0 = lnnz > 0 ? (A->f32 ? (double) (float) va[0] : va[0]) : 0.0;
+		#pragma omp parallel for num_threads(spmv::host_threads()) reduction(+ : differs)
+		for (long j = 0; j < lnnz; j++)
+			differs += (A->f32 ? (double) (float) va[j] : va[j]) != v0;
+		uniform = uniform && differs == 0 && v0 == v0;
+	}
+	std::vector<int> seg_blk((size_t) std::max<long>(S, 1) * (B + 1), 0);
+	std::vector<int> pcol((size_t) lnnz);
+	std::vector<unsigned short> plrow((size_t) lnnz);
+	std::vector<double> pval(uniform ? 0 : (size_t) lnnz);
+	#pragma omp parallel num_threads(spmv::host_threads())
+	{
+		std::vector<int> pos((size_t) B + 1);
+		#pragma omp for schedule(dynamic, 8)
+		for (long sgm = 0; sgm < S; sgm++)
+		{
+			const int r0 = seg_row[sgm], r1 = seg_row[sgm + 1];
+			std::fill(pos.begin(), pos.end(), 0);
+			for (long j = rp[r0]; j < rp[r1]; j++)
+				pos[(size_t) (ci[j] / W) + 1]++;
+			int * sb = seg_blk.data() + (size_t) sgm * (B + 1);
+			sb[0] = rp[r0];
+			for (int b = 0; b < B; b++)
+				sb[b + 1] = sb[b] + pos[(size_t) b + 1];
+			for (int b = 0; b <= B; b++)
+				pos[(size_t) b] = sb[b];
+			for (int r = r0; r < r1; r++)
+				for (long j = rp[r]; j < rp[r + 1]; j++)
+				{
+					const int at = pos[(size_t) (ci[j] / W)]++;
+					pcol[(size_t) at] = ci[j];
+					plrow[(size_t) at] = (unsigned short) (r - r0);
+					if (!uniform)
+						pval[(size_t) at] = va[j];
+				}
+		}
+	}
+	int rc = upload_ints(seg_row.data(), seg_row.size(), &A->d_coob_seg_row) || upload_ints(seg_blk.data(), seg_blk.size(), &A->d_coob_seg_blk) ||
+	         upload_ints(pcol.data(), (size_t) lnnz, &A->d_col) || dev_alloc_bytes((void **) &A->d_coob_lrow, ((size_t) lnnz + STREAM_SLACK) * 2);
+	if (rc)
+		return 1;
+	if (lnnz)
+		HIP_TRY(hipMemcpy(A->d_coob_lrow, plrow.data(), (size_t) lnnz * 2, hipMemcpyHostToDevice));
+	if (!uniform && upload_values(A, pval.data(), (size_t) lnnz, &A->d_val))
+		return 1;
+	if (uniform)
+	{
+		A->cfg.unit = 1;
+		A->cfg.unit_value = v0;
+	}
+	int max_rows = 0;
+	for (long sgm = 0; sgm < S; sgm++)
+		max_rows = std::max(max_rows, seg_row[sgm + 1] - seg_row[sgm]);
+	A->coob_segs = (int) S;
+	A->coob_blocks = B;
+	A->coob_lds = (int) (((long) std::max(max_rows, 1) * A->vbytes + 15) / 16 * 16);
+	A->cfg.map = xcd_map_uniform(1, 0);
+	A->mem_footprint = (double) lnnz * (6 + (uniform ? 0 : A->vbytes)) + (S + 1) * 4.0 + (double) S * (B + 1) * 4;
+	snprintf(A->format_name, sizeof(A->format_name), "MI355X_COOB_s%ld_b%d%s_%s", S, B, uniform ? "_unit" : "", pf);
+	snprintf(A->kernel_name, sizeof(A->kernel_name), "coo_blocked_kernel");
+	return 0;
+}
+
 static int
 build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va)
 {
@@ -1153,6 +1270,11 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 		}
 		case SPMV_MI355X_COO:
 		{
+			if (o.col_blocks != 0)
+			{
+				rc = build_coo_blocked(A, rp, ci, va, o.col_blocks, pf);
+				break;
+			}
 			rc = upload_ints(rp, (size_t) lm + 1, &A->d_row_ptr) || upload_ints(ci, (size_t) lnnz, &A->d_col) ||
 			     upload_values(A, va, (size_t) lnnz, &A->d_val) || dev_alloc(&A->d_rowind, (size_t) lnnz);
 			if (rc)
@@ -1249,6 +1371,12 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 					(int) A->sell_slices, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_COO:
+			if (A->coob_segs > 0)
+			{
+				rc = launch_coo_blocked(A->f32, A->d_coob_seg_row, A->d_coob_seg_blk, A->d_col, A->d_coob_lrow, A->d_val, x, y, A->coob_segs,
+						A->coob_blocks, A->coob_lds, cfg, st, &grid);
+				break;
+			}
 			rc = launch_coo(A->f32, A->coo_k, A->d_rowind, A->d_col, A->d_val, x, y, (int) A->m, A->nnz, A->coo_num_waves,
 					A->d_carry_row, A->d_carry_val, cfg, st, &grid);
 			break;

@@ -67,6 +67,7 @@ struct MI355XFormat : Matrix_Format
 		o.merge_items = env_int("SPMV_MI355X_MERGE_ITEMS", 0);
 		o.stream_mode = env_int("SPMV_MI355X_STREAM_MODE", 0);
 		o.rows_per_group = env_int("SPMV_MI355X_ROWS_PER_GROUP", 0);
+		o.col_blocks = env_int("SPMV_MI355X_COL_BLOCKS", 0);
 		o.sell_delta = env_int("SPMV_MI355X_SELL_DELTA", 0);
 		o.sell_split = env_int("SPMV_MI355X_SELL_SPLIT", 0);
 		o.xcd_remap = env_int("SPMV_MI355X_XCD_REMAP", 0);

@@ -61,6 +61,9 @@ VARIANTS = [
     ("coo", {}, False),
     ("coo", {"merge_items": 2}, False),
     ("coo", {"merge_items": 8}, False),
+    ("coo", {"col_blocks": -1}, False),                  # column-blocked COO: segments of rows in LDS, entries by column block
+    ("coo", {"col_blocks": 3}, False),
+    ("coo", {"col_blocks": 64}, False),
 ]
 IDS = [f"{f}-{'-'.join(f'{k}{v}' for k, v in o.items()) or 'default'}" for f, o, _ in VARIANTS]
 

@@ -38,6 +38,8 @@ def variants(dts):
         v.append(("sell_c_sigma", {"sell_c": 64, "sell_split": sp}))
     for k in (2, 4, 8):
         v.append(("coo", {"merge_items": k}))
+    for b in (-1, 8, 16, 32, 64):
+        v.append(("coo", {"col_blocks": b}))
     return v
 
 
