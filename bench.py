@@ -102,7 +102,11 @@ def load_traffic(workload, fmt, dtype, kernel):
                         # SELL instead of the delta layout, is a different kernel with different traffic)
                         if rec.get("workload") == workload and rec.get("format") == fmt and rec.get("dtype") == dtype \
                                 and rec.get("scale", 1.0) == 1.0 and rec.get("kernel", "").split("<")[0] == kernel:
+                            # a format that needs several dispatches of its kernel per SpMV (column-blocked COO: one per 512
+                            # segments) records the per-dispatch figure and how many there are: traffic is per SpMV
                             best = rec.get("hbm_bytes_per_launch")
+                            if best is not None:
+                                best = int(best * rec.get("dispatches_per_spmv", 1))
             except Exception:
                 pass
     return best
