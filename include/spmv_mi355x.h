@@ -85,7 +85,7 @@ typedef struct {
 	int  rows_per_group;    /* CSR_VECTOR: consecutive rows a lane group keeps in flight together (1, 2 or 4; 2 and 4 need
 	                           lanes_per_row >= 8); 0 = auto                                                        */
 	int  col_blocks;        /* COO: 0 = row-sorted COO (the reference's layout); -1 = column-blocked COO for graph matrices with
-	                           blocks of ~1 MiB of x; > 0 = that many column blocks. Rows are cut into segments whose y lives in
+	                           blocks of ~384 KiB of x; > 0 = that many column blocks. Rows are cut into segments whose y lives in
 	                           LDS, entries are ordered by column block inside a segment (csrc/kernels_coo.hip)            */
 } spmv_mi355x_opts;
 

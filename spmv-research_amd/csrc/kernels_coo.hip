@@ -189,12 +189,13 @@ launch_coo(bool f32, int items_per_lane, const int * rowind, const int * col, co
 // For graph matrices (soc-LiveJournal1: 14 entries per row scattered over a 39 MB x) the row-sorted kernels sit on the
 // fabric's random-sector rate: every gather misses the 4 MiB L2 of its XCD. Here the rows are cut into segments of at most
 // COOB_ROWS rows (their y lives in LDS), 512 segments run at a time — all resident, two workgroups per CU — and every
-// workgroup walks ITS entries column block by column block (blocks of ~1 MiB of x), adding v*x[col] into the LDS copy of y
+// workgroup walks ITS entries column block by column block (blocks of ~384 KiB of x, a barrier of the workgroup after every block), adding v*x[col] into the LDS copy of y
 // with LDS atomics. Segments hold equal numbers of entries, so the workgroups sweep the column blocks in step and the block
 // of x being gathered stays in every XCD's L2. Entry = (column: 4 B, row inside the segment: 2 B, value unless all values
 // are equal). The LDS atomics make the order of a row's additions run-dependent (last-bit differences; bar 1e-12 / 1e-5).
 constexpr int COOB_THREADS = 512;
 constexpr int COOB_U = 4;
+constexpr int COOB_SYNC_EVERY = 1;
 
 template <typename T, bool UNIT>
 __global__ __launch_bounds__(COOB_THREADS) void
@@ -241,6 +242,8 @@ coo_blocked_kernel(const int * __restrict__ seg_row, const int * __restrict__ se
 				if (c[u] >= 0)
 					unsafeAtomicAdd(&ys[r[u]], v[u] * xv[u]);
 		}
+		if (COOB_SYNC_EVERY > 0 && (b + 1) % COOB_SYNC_EVERY == 0)
+			__syncthreads();                 // keep the waves of the workgroup on the same column block
 	}
 	__syncthreads();
 	for (int i = threadIdx.x; i < nrows; i += COOB_THREADS)

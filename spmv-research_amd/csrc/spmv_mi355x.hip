@@ -326,7 +326,7 @@ build_coo_blocked(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 	}
 	else
 	{
-		W = std::max<long>(1024, (1L << 20) / A->vbytes);            // ~1 MiB of x per block (an XCD's L2 is 4 MiB; flat between 24 and 96 blocks on the soc-LiveJournal1 twin)
+		W = std::max<long>(1024, (384L << 10) / A->vbytes);          // ~384 KiB of x per block: with the per-block barrier 96-128 blocks are best on the soc-LiveJournal1 twin (420-440 us; 37: 470, 192: 495, 256: 600)
 		B = (int) std::max<long>(1, (n + W - 1) / W);
 	}
 	B = (int) std::max<long>(1, (n + W - 1) / W);
