@@ -5,24 +5,27 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 torch.distributed.run with one rank per GPU (RCCL). Rank 0 prints ONE JSON line.
 
 A "step" is one y = A*x over the whole matrix with the matrix, x and y already resident in HBM:
-  N = 1 : one launch of the selected HIP kernel (through the C ABI, include/spmv_mi355x.h);
-  N > 1 : row-block partition (nnz-balanced, the reference's per-thread partitioner applied to GPUs, SURVEY §8e);
-          every step = RCCL allgather of x over xGMI (forced every step, as in a solver where x changes) overlapped
-          with the local-column part of the block, then the remote-column part accumulated into y. Total work is
-          fixed as N grows -> "scaling": "strong".
+  N = 1 : one launch of the selected HIP kernel through the C ABI (include/spmv_mi355x.h);
+  N > 1 : row-partitioned SpMV with the x exchange forced every step (spmv-research_amd/python/bench_multi.py).
+          Total work is fixed as N grows -> "scaling": "strong".
 
-Default workload: 'nlpkkt240' (config 5 of BASELINE.json: 28.0 M rows, ~770 M non-zeros, fp64), default format
-SELL-64-sigma with delta-compressed column indices (the engine's fastest format for it; `--format csr_stream` is the
-fastest kernel on plain CSR storage) — the largest
+Headline workload: 'nlpkkt240' (config 5 of BASELINE.json: 28.0 M rows, ~770 M non-zeros, fp64) — the largest
 single-GPU configuration, the one the multi-GPU target is quoted on, and far larger than the 256 MiB Infinity Cache,
-so the algorithmic GB/s below is real HBM traffic. The matrices are synthetic twins (no SuiteSparse file exists in
-the reference tree and there is no network): see spmv-research_amd/host/synthetic.cpp and DESIGN.md.
+so its algorithmic GB/s is real HBM traffic. At N = 1 the same run also times configs 1-4 (cant, scircuit, pwtk fp32,
+soc-LiveJournal1) with the kernel BASELINE.json NAMES for them and with the engine's best kernel, and reports them
+under "configs" — so the driver-run record carries all five fractions.
+The matrices are synthetic twins (no SuiteSparse file exists in the reference tree and there is no network; a real
+file under $SPMV_MTX_DIR/<name>.mtx is loaded through the product's own Matrix-Market reader instead).
 
 metric/value: GFLOP/s = 2*nnz / t (true stored nnz; the reference's printed GFLOPS is ~2x inflated for general
-matrices). roofline.achieved: algorithmic bytes B_alg = nnz*(sizeof(V)+4) + (m+1)*4 + (n+m)*sizeof(V)
+matrices). roofline.achieved: ALGORITHMIC bytes B_alg = nnz*(sizeof(V)+4) + (m+1)*4 + (n+m)*sizeof(V)
 per launch / mean kernel time from HIP events recorded on the launch stream over the timed region.
+roofline.frac == roofline.frac_algorithmic is that CSR-normalised figure; roofline.frac_hbm_measured is the PMC
+traffic of the same kernel build / time / peak (only when profiles/traffic_*.json holds a record taken with these
+kernel sources and this format).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,14 +37,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spmv-research_amd", "python"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+INFINITY_CACHE_BYTES = 256 << 20
+WORKLOADS = ("cant", "scircuit", "pwtk", "soc-LiveJournal1", "nlpkkt240")
+# the engine's best kernel per workload (what `bench.py --workload W` times when --format is not given)
 DEFAULT_FORMAT = {"nlpkkt240": "sell_c_sigma", "cant": "csr_stream", "pwtk": "csr_stream",
                   "scircuit": "csr_vector", "soc-LiveJournal1": "coo"}
 DEFAULT_DTYPE = {"pwtk": "f32"}
 # options that go with a default format (only when --format is not given)
-DEFAULT_OPTS = {"soc-LiveJournal1": {"col_blocks": -1}}        # column-blocked COO: 0.42 ms against 0.76 ms for merge-path
+DEFAULT_OPTS = {"soc-LiveJournal1": {"col_blocks": -1}}        # column-blocked COO
+# the kernel BASELINE.json's `configs` NAME for each workload (format, options)
+NAMED_KERNEL = {
+    "cant": ("csr_vector", {}),                           # config 1: CSR fp64 (the CPU path's format)
+    "scircuit": ("csr_vector", {"lanes_per_row": 64}),   # config 2: CSR-Vector, one wavefront per row
+    "pwtk": ("sell_c_sigma", {}),                         # config 3: SELL-C-sigma fp32
+    "soc-LiveJournal1": ("csr_merge", {}),                # config 4: merge-based CSR
+    "nlpkkt240": ("csr_stream", {}),                      # config 5: row-partitioned CSR (plain CSR storage)
+}
+# configs 1-4: timed after the headline at N = 1
+SMALL_CONFIGS = ("cant", "scircuit", "pwtk", "soc-LiveJournal1")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -49,34 +65,44 @@ def parse():
     ap.add_argument("--workload", default="nlpkkt240",
                     help="cant | scircuit | pwtk | soc-LiveJournal1 | nlpkkt240 (synthetic twins)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (tests only; invalid as a result)")
-    ap.add_argument("--format", default=None, help="csr_scalar|csr_vector|csr_merge|sell_c_sigma|coo")
+    ap.add_argument("--format", default=None, help="csr_scalar|csr_vector|csr_stream|csr_merge|sell_c_sigma|coo")
     ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
+    ap.add_argument("--opt", action="append", default=[], help="key=value for spmv_mi355x_opts (repeatable)")
     ap.add_argument("--lanes-per-row", type=int, default=0)
     ap.add_argument("--sell-c", type=int, default=0)
     ap.add_argument("--sell-sigma", type=int, default=0)
     ap.add_argument("--merge-items", type=int, default=0)
     ap.add_argument("--nontemporal", type=int, default=0)
-    ap.add_argument("--col-blocks", type=int, default=0, help="coo: -1 = column-blocked COO with ~1 MiB blocks of x, >0 = that many blocks")
+    ap.add_argument("--col-blocks", type=int, default=0, help="coo / csr_merge: -1 = column-blocked with ~384 KiB blocks of x, >0 = that many blocks")
     ap.add_argument("--xcd-remap", type=int, default=0)
-    ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap the x exchange with the local-column part")
+    ap.add_argument("--jitter", type=float, default=0.0,
+                    help="nlpkkt240 only: fraction of rows whose off-diagonal columns are perturbed by up to +-jitter-span "
+                         "(sensitivity of the compressed-index format to the twin's regularity; invalid as the headline)")
+    ap.add_argument("--jitter-span", type=int, default=3)
+    ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
+                    help="time configs 1-4 (named + best kernel) after the headline; auto = on for the default headline at N = 1")
+    ap.add_argument("--configs-steps", type=int, default=300)
+    ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap the x exchange with the rows/columns that need no remote x")
     ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "p2p"],
                     help="N>1: RCCL allgather of the padded x slices, or grouped send/recv of only the sub-ranges each row "
                          "block reads (same result); auto = time both in the warm-up and keep the faster")
     ap.add_argument("--partition", default="auto", choices=["auto", "rows", "graph"],
                     help="N>1: 'rows' = the reference's nnz-balanced contiguous row blocks of A as it is; 'graph' = the same balance "
-                         "cut out of a breadth-first order of the matrix graph (the engine runs on P A P^T; x and y live in that "
-                         "numbering); 'auto' = whichever makes the busiest rank read fewer remote x entries")
+                         "cut out of a breadth-first order of the matrix graph; 'auto' = whichever makes the busiest rank read "
+                         "fewer remote x entries")
     ap.add_argument("--layout", default="auto", choices=["auto", "original", "padded"],
                     help="N>1 with the graph partition: 'original' = every rank keeps a full-length x in the matrix's ORIGINAL "
-                         "numbering (rows keep the column patterns the format compresses) and the halo moves by pack -> send/recv -> "
-                         "scatter; 'padded' = P A P^T with x as padded slices exchanged in place; 'auto' = original when its "
-                         "exchange validates on every rank")
+                         "numbering and the halo moves by pack -> send/recv -> scatter; 'padded' = P A P^T with x as padded "
+                         "slices exchanged in place")
     ap.add_argument("--halo", default="auto", choices=["auto", "alltoall", "p2p"],
                     help="original layout: how the packed halo segments move (auto = all_to_all_single if it validates, else p2p)")
+    ap.add_argument("--variants", default="auto", choices=["auto", "both", "one"],
+                    help="N>1: 'both' = time the north-star scheme (row blocks + allgather(x)) AND the auto choice in one run and "
+                         "report both under \"variants\" (value = the faster); auto = both unless --partition/--exchange is given")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def algorithmic_bytes(m, n, nnz, vbytes):
@@ -87,28 +113,54 @@ def kkt_edge(scale):
     return max(4, int(round(240 * scale ** (1.0 / 3.0))))
 
 
-def load_traffic(workload, fmt, dtype, kernel):
-    """HBM bytes per launch from the rocprofv3 PMC passes (tools/collect_traffic.py -> profiles/traffic_*.json)."""
+_SRC_SHA = None
+
+
+def kernel_source_sha():
+    """Fingerprint of the device code (csrc/*.hip, *.hpp): a PMC traffic record is only attached to a run whose kernels are
+    the ones the counters were collected on."""
+    global _SRC_SHA
+    if _SRC_SHA is None:
+        h = hashlib.sha256()
+        d = os.path.join(ROOT, "spmv-research_amd", "csrc")
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".hpp")):
+                h.update(f.encode())
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(fh.read())
+        _SRC_SHA = h.hexdigest()[:16]
+    return _SRC_SHA
+
+
+def load_traffic(workload, format_name, dtype, kernel, src_sha=None, pdir=None):
+    """HBM bytes per SpMV from the rocprofv3 PMC passes (tools/collect_traffic.py -> profiles/traffic_*.json), or None.
+
+    A record is used only when it was collected on the SAME kernel (name), the SAME converted format (the handle's
+    format_name encodes the options and block counts) and — when the record carries one — the same kernel sources."""
     best = None
-    pdir = os.path.join(ROOT, "profiles")
+    pdir = pdir or os.path.join(ROOT, "profiles")
     if not os.path.isdir(pdir):
         return None
+    src_sha = src_sha or kernel_source_sha()
     for f in sorted(os.listdir(pdir)):
-        if f.startswith("traffic_") and f.endswith(".json"):
-            try:
-                with open(os.path.join(pdir, f)) as fh:
-                    for rec in json.load(fh).get("records", []):
-                        # the record must be of the kernel that actually ran (a non-default option set, e.g. plain
-                        # SELL instead of the delta layout, is a different kernel with different traffic)
-                        if rec.get("workload") == workload and rec.get("format") == fmt and rec.get("dtype") == dtype \
-                                and rec.get("scale", 1.0) == 1.0 and rec.get("kernel", "").split("<")[0] == kernel:
-                            # a format that needs several dispatches of its kernel per SpMV (column-blocked COO: one per 512
-                            # segments) records the per-dispatch figure and how many there are: traffic is per SpMV
-                            best = rec.get("hbm_bytes_per_launch")
-                            if best is not None:
-                                best = int(best * rec.get("dispatches_per_spmv", 1))
-            except Exception:
-                pass
+        if not (f.startswith("traffic_") and f.endswith(".json")):
+            continue
+        try:
+            with open(os.path.join(pdir, f)) as fh:
+                recs = json.load(fh).get("records", [])
+        except Exception:
+            continue
+        for rec in recs:
+            if rec.get("workload") != workload or rec.get("dtype") != dtype or rec.get("scale", 1.0) != 1.0:
+                continue
+            if rec.get("kernel", "").split("<")[0] != kernel or rec.get("format_name") != format_name:
+                continue
+            if rec.get("kernel_src_sha") != src_sha:
+                continue
+            v = rec.get("hbm_bytes_per_launch")
+            if v is not None:
+                # a format that needs several dispatches of its kernel per SpMV records the per-dispatch figure
+                best = int(v * rec.get("dispatches_per_spmv", 1))
     return best
 
 
@@ -146,43 +198,7 @@ def cpu_share():
     return n
 
 
-def main():
-    args = parse()
-    # Host threads: the GPU box shows all 256 cores but a job owns a cgroup CPU quota (16 cores per GPU); an OpenMP team
-    # of 256 burns the quota in a few ms and the kernel then freezes the whole process — the thread feeding the GPU
-    # included — until the next 100 ms period (csrc/host_threads.hpp has the measurement). torch.distributed.run on the
-    # other hand pins OMP_NUM_THREADS=1. Either way: give every rank its share, before any OpenMP runtime starts.
-    share = max(1, min(cpu_share(), len(os.sched_getaffinity(0))) // int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
-    if "OMP_NUM_THREADS" not in os.environ or (int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ["OMP_NUM_THREADS"] == "1"):
-        os.environ["OMP_NUM_THREADS"] = str(min(share, 16) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else share)
-    os.environ.setdefault("KMP_BLOCKTIME", "0")
-    import torch
-    import spmv_host as H
-    import spmv_mi355x as E
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    local_rank %= torch.cuda.device_count()       # a gloo rehearsal may put several ranks on one GPU; RCCL runs get one each
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend)
-
-    workload = args.workload
-    fmt = args.format or DEFAULT_FORMAT.get(workload, "csr_vector")
-    dts = args.dtype or DEFAULT_DTYPE.get(workload, "f64")
-    np_dtype = np.float64 if dts == "f64" else np.float32
-    t_dtype = torch.float64 if dts == "f64" else torch.float32
-    vbytes = 8 if dts == "f64" else 4
+def collect_opts(args, workload):
     opts = dict(DEFAULT_OPTS.get(workload, {})) if not args.format else {}
     if args.col_blocks:
         opts["col_blocks"] = args.col_blocks
@@ -190,440 +206,279 @@ def main():
                  ("merge_items", args.merge_items), ("nontemporal", args.nontemporal), ("xcd_remap", args.xcd_remap)):
         if v:
             opts[k] = v
+    for kv in args.opt:
+        k, v = kv.split("=")
+        opts[k] = int(v)
+    return opts
 
-    # ------------------------------------------------------------------ matrix (synthetic twin), row partition
-    t_gen = time.time()
+
+def load_workload(H, workload, scale, jitter=0.0, jitter_span=3):
+    """The CSR of a BASELINE.json workload: a real Matrix-Market file when $SPMV_MTX_DIR holds one (never fetched), else the
+    synthetic twin. Returns (A, data) with data = "synthetic" | "file:<path>"."""
+    mdir = os.environ.get("SPMV_MTX_DIR")
+    if mdir and scale == 1.0 and not jitter:
+        for ext in (".mtx", ".mtx.gz", ".mtx.zst", ".tar.gz"):
+            p = os.path.join(mdir, workload + ext)
+            if os.path.exists(p):
+                info, rp, ci, va = H.mtx_to_csr(p)
+                return dict(m=info["m"], n=info["n"], nnz=len(ci), row_ptr=rp, col_idx=ci, values=va), "file:" + p
     if workload == "nlpkkt240":
-        N = kkt_edge(args.scale)
-        if world == 1:
-            A = H.gen_kkt(N)
-            m = n = A["m"]
-            nnz_total = A["nnz"]
-            row_ptr_g = A["row_ptr"]
-            blk = A
-            r0, r1 = 0, m
-        elif args.partition == "rows":
-            row_ptr_g = H.gen_kkt_row_ptr(N)                # row blocks of A as it is: every rank builds only its own
-            m = n = len(row_ptr_g) - 1
-            nnz_total = int(row_ptr_g[m])
-        else:
-            A = H.gen_kkt(N)                                # the graph partition looks at the whole structure
-            m = n = A["m"]
-            nnz_total = A["nnz"]
-            row_ptr_g = A["row_ptr"]
-    else:
-        A = H.gen_named(workload, args.scale)
-        m, n, nnz_total, row_ptr_g = A["m"], A["n"], A["nnz"], A["row_ptr"]
-        blk = A
-        r0, r1 = 0, m
-    offsets = None
-    partition_info = None
-    layout = "padded"                                       # N>1: how x is laid out on a rank (see --layout)
-    packed = None
-    blk_pair = None
-    x_host = np.random.default_rng(14).uniform(-1.0, 1.0, n).astype(np_dtype)   # global x (same on every rank)
-    if world > 1:
-        import spmv_dist as D
-        if workload == "nlpkkt240" and args.partition == "rows":
-            offsets = D.row_partition(row_ptr_g, world)      # nnz-balanced contiguous row blocks (parallel_util.h:156-184)
-            r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
-            blk = H.gen_kkt_block(kkt_edge(args.scale), r0, r1)
-            partition_info = {"kind": "rows"}
-        else:
-            # deterministic host code on the same matrix: every rank arrives at the same partition without talking
-            part = D.graph_partition(row_ptr_g, A["col_idx"], m, n, world, args.partition)
-            offsets = part.offsets
-            r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
-            blk = D.partition_block(row_ptr_g, A["col_idx"], A["values"], part, rank)
-            partition_info = {"kind": part.kind, "remote_x_entries_per_rank": [int(v) for v in part.volume],
-                              "considered_max_remote_x_entries": part.considered}
-            if part.kind == "graph" and args.layout != "padded":
-                # original-numbering layout: validate its exchange BEFORE anything is built on it; all ranks take the same branch
-                owner = part.owner()
-                send, recv = H.halo_lists(row_ptr_g, A["col_idx"], owner, world, rank)
-                mine = np.flatnonzero(owner == rank)
-                mine_dev = torch.from_numpy(mine).cuda()
-                x_orig = torch.zeros(n, dtype=t_dtype, device="cuda")
-                want = np.concatenate([x_host[l] for l in recv]) if sum(len(l) for l in recv) else np.zeros(0, np_dtype)
-                flag = None
-                # one all_to_all_single per step if the backend delivers it correctly, else grouped isend/irecv
-                for xmode in (("alltoall", "p2p") if args.halo == "auto" else (args.halo,)):
-                    ok = 1
-                    try:
-                        x_orig.zero_()
-                        x_orig[mine_dev] = torch.from_numpy(x_host[mine]).cuda()
-                        packed = D.PackedExchange(dist, torch, x_orig, send, recv, rank, world, xmode)
-                        packed.finish(packed.start())
-                        torch.cuda.synchronize()
-                        got = x_orig[packed.recv_idx].cpu().numpy()
-                        if not np.array_equal(got, want):
-                            ok = 0
-                            print(f"[bench] rank {rank}: packed halo exchange ({xmode}) delivered {int((got != want).sum())} wrong "
-                                  f"entries of {len(want)}", file=sys.stderr)
-                    except Exception as e:
-                        ok = 0
-                        partition_info["packed_exchange_error_" + xmode] = repr(e)[:200]
-                        print(f"[bench] rank {rank}: packed halo exchange ({xmode}) failed: {repr(e)[:300]}", file=sys.stderr)
-                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                    if int(flag.item()) == 1:
-                        break
-                del mine_dev
-                if int(flag.item()) == 1:
-                    layout = "original"
-                    # the rank's rows, interior rows first (all columns owned: computed while the halo is in flight), boundary
-                    # rows after them (computed when it has arrived); every row whole, in the matrix's own entry order
-                    blk = D.interior_boundary_blocks(row_ptr_g, A["col_idx"], A["values"], owner, rank)
-                    assert np.array_equal(np.sort(blk["rows"]), mine)
-                    partition_info["interior_rows"], partition_info["boundary_rows"] = int(blk["split"]), int(blk["m"] - blk["split"])
-                    if args.overlap:
-                        blk_pair = (blk["interior"], blk["boundary"])
-                elif args.layout == "original":
-                    raise SystemExit("--layout original: the packed halo exchange did not validate on every rank")
-                else:
-                    packed = None
-                del owner
-            partition_info["layout"] = layout
-            del A, part
-        assert m == n, "row-partitioned allgather(x) assumes a square matrix (x slices follow the row blocks)"
-        if layout == "original":
-            padded, n_x = n, n                              # full-length x in the original numbering, original column indices
-        else:
-            padded = D.padded_len(offsets)
-            D.to_padded_columns(blk["col_idx"], offsets, padded)   # x lives as `world` slices padded to a common length
-            n_x = padded * world
-    else:
-        padded = n
-        n_x = n
-    t_gen = time.time() - t_gen
-    lm, lnnz = blk["m"], blk["nnz"]
+        A = H.gen_kkt(kkt_edge(scale))
+        if jitter:
+            H.jitter_columns(A, jitter, jitter_span)
+        return A, "synthetic"
+    return H.gen_named(workload, scale), "synthetic"
 
-    # ------------------------------------------------------------------ device state
-    t_conv = time.time()
-    if world == 1:
-        mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype, **opts)]
-    elif layout == "original" and args.overlap:
-        # (handle, first row of y it writes, phase: 0 = while the halo is in flight, 1 = after it has arrived)
-        launches = [(E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n_x, fmt, np_dtype, **opts), first, phase)
-                    for b, first, phase in ((blk_pair[0], 0, 0), (blk_pair[1], blk["split"], 1)) if b["m"] > 0]
-        mats = [l[0] for l in launches]
-        blk_pair = None
-    elif args.overlap:
-        c0, c1 = rank * padded, rank * padded + (r1 - r0)
-        mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype,
-                         col_begin=c0, col_end=c1, col_filter_mode=1, **opts),
-                E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype,
-                         col_begin=c0, col_end=c1, col_filter_mode=2, **opts)]
-    else:
-        mats = [E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], lm, n_x, fmt, np_dtype, **opts)]
-    t_conv = time.time() - t_conv
 
-    x_full = x_orig if layout == "original" else torch.zeros(n_x, dtype=t_dtype, device="cuda")
-    if world == 1:
-        x_full.copy_(torch.from_numpy(x_host))
-        x_loc = x_full
-    elif layout == "original":
-        x_loc = x_full                                           # own entries already in place (validated above)
-    else:
-        x_loc = x_full[rank * padded:(rank + 1) * padded]         # in-place allgather: own slice lives inside x_full
-        x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
-    # RCCL gathers in place (send buffer = own slice of the receive buffer); gloo stages through the host and wants a
-    # separate send buffer
-    x_send = x_loc if (world == 1 or args.backend == "nccl") else x_loc.clone()
-    y = torch.full((lm + 64,), 1.0, dtype=t_dtype, device="cuda")  # driver canary (bench_spmv.cpp:606-609)
-    compute = torch.cuda.current_stream()
-    sp = compute.cuda_stream
-
-    use_p2p = False
-    exch = None
-
-    def step():
-        if world == 1:
-            mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
-            return
-        if layout == "original":
-            reqs = packed.start()                               # pack + grouped send/recv of the halo
-            if args.overlap:
-                for M, first, phase in launches:
-                    if phase == 0:                              # interior rows: every column is owned by this rank
-                        M.spmv_device(x_full.data_ptr(), y.data_ptr() + first * vbytes, 0, sp)
-                packed.finish(reqs)                             # wait + scatter to the original positions
-                for M, first, phase in launches:
-                    if phase == 1:                              # boundary rows
-                        M.spmv_device(x_full.data_ptr(), y.data_ptr() + first * vbytes, 0, sp)
-            else:
-                packed.finish(reqs)
-                mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
-            return
-        if use_p2p:
-            reqs = exch.start()
-        else:
-            reqs = [dist.all_gather_into_tensor(x_full, x_send, async_op=True)]
-        if args.overlap:
-            mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)      # local columns: only the own slice of x
-            for r in reqs:
-                r.wait()
-            mats[1].spmv_device(x_full.data_ptr(), y.data_ptr(), 1, sp)      # remote columns, y += ...
-        else:
-            for r in reqs:
-                r.wait()
-            mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    exchange_info = None
-    if world > 1 and layout == "original":
-        exchange_info = {"chosen": "packed halo " + packed.mode, "recv_x_entries": packed.recv_elems, "send_x_entries": packed.send_elems,
-                         "recv_max_from_one_peer": packed.recv_max_from_one_peer}
-    if world > 1 and layout == "padded":
-        # one untimed exchange, checked: every rank must end up with the same padded x. If the in-place form (send buffer
-        # = own slice of the receive buffer) is not honoured by the backend, fall back to a separate send buffer.
-        import spmv_dist as D
-        x_expect = torch.from_numpy(D.scatter_x_padded(x_host, offsets, padded)).cuda()
-        inplace_ok = True
-        try:
-            dist.all_gather_into_tensor(x_full, x_send)
-            torch.cuda.synchronize()
-        except Exception as e:                                  # a backend that refuses the aliased buffers outright
-            print(f"[bench] in-place allgather refused ({repr(e)[:120]}); using a separate send buffer", file=sys.stderr)
-            inplace_ok = False
-        agree = torch.tensor([1 if (inplace_ok and torch.equal(x_full, x_expect)) else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(agree, op=dist.ReduceOp.MIN)             # every rank takes the same branch (same number of collectives)
-        if int(agree.item()) == 0:
-            x_full.zero_()
-            x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
-            x_send = x_loc.clone()
-            dist.all_gather_into_tensor(x_full, x_send)
-            torch.cuda.synchronize()
-            if not torch.equal(x_full, x_expect):
-                raise SystemExit("allgather(x) did not produce the expected padded vector")
-        exchange_info = {"chosen": "allgather"}
-        if args.exchange != "allgather":
-            # trimmed exchange: validated against the same expectation on the ranges it promises to deliver; every rank
-            # must agree that it works, otherwise all stay with the allgather
-            ok = 1
-            try:
-                exch = D.TrimmedExchange(dist, x_full, padded, rank, world,
-                                         ranges=D.needed_subranges(blk["col_idx"], padded, world))
-                x_full.zero_()
-                x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
-                for r in exch.start():
-                    r.wait()
-                torch.cuda.synchronize()
-                for a, b in exch.delivered():
-                    if not torch.equal(x_full[a:b], x_expect[a:b]):
-                        ok = 0
-            except Exception as e:                      # e.g. a rehearsal backend without device send/recv
-                ok = 0
-                exchange_info["p2p_error"] = repr(e)[:200]
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                exchange_info["p2p_recv_fraction_of_allgather"] = round(exch.recv_elems / float((world - 1) * padded), 4)
-                if args.exchange == "p2p":
-                    use_p2p = True
-                else:
-                    # auto: a few untimed steps of each, max over ranks, keep the faster
-                    t_each = {}
-                    for name, flagv in (("allgather", False), ("p2p", True)):
-                        use_p2p = flagv
-                        for _ in range(3):
-                            step()
-                        if dist is not None:
-                            dist.barrier()
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        for _ in range(10):
-                            step()
-                        torch.cuda.synchronize()
-                        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                        t_each[name] = float(tt.item()) / 10 * 1e3
-                    use_p2p = t_each["p2p"] < t_each["allgather"]
-                    exchange_info.update({"allgather_ms": round(t_each["allgather"], 4), "p2p_ms": round(t_each["p2p"], 4)})
-                exchange_info["chosen"] = "p2p" if use_p2p else "allgather"
-            if not use_p2p:
-                # leave x_full complete for the allgather path
-                x_full.zero_()
-                x_loc[:r1 - r0].copy_(torch.from_numpy(x_host[r0:r1]))
-                dist.all_gather_into_tensor(x_full, x_send)
-                torch.cuda.synchronize()
-        del x_expect
-    comm_only_ms = kernels_only_ms = None
-    if world > 1:
-        # untimed breakdown for the scaling report: the exchange alone and the two kernels alone
-        def comm_only():
-            if layout == "original":
-                packed.finish(packed.start())
-                return
-            for r in (exch.start() if use_p2p else [dist.all_gather_into_tensor(x_full, x_send, async_op=True)]):
-                r.wait()
-
-        def kernels_only():
-            if layout == "original" and args.overlap:
-                for M, first, _phase in launches:
-                    M.spmv_device(x_full.data_ptr(), y.data_ptr() + first * vbytes, 0, sp)
-                return
-            mats[0].spmv_device(x_full.data_ptr(), y.data_ptr(), 0, sp)
-            if args.overlap:
-                mats[1].spmv_device(x_full.data_ptr(), y.data_ptr(), 1, sp)
-
-        parts = []
-        for fn in (comm_only, kernels_only):
-            for _ in range(3):
-                fn()
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                fn()
-            torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            parts.append(float(tt.item()) / 10 * 1e3)
-        comm_only_ms, kernels_only_ms = parts
-    for _ in range(args.warmup):
-        step()
-    barrier()
-
-    # ------------------------------------------------------------------ timed region
-    K = args.steps
-    kernel_ms = None
-    if world == 1:
-        t0 = time.perf_counter()
-        kernel_ms = mats[0].time_device(x_full.data_ptr(), y.data_ptr(), K, sp)   # HIP events on the launch stream
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-    else:
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-        t0 = time.perf_counter()
-        for i in range(K):
-            ev[i][0].record(compute)
-            step()
-            ev[i][1].record(compute)
-        barrier()
-        t1 = time.perf_counter()
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))              # per step on the compute stream
-    elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = elapsed / K * 1e3
-
-    # ------------------------------------------------------------------ sanity: sampled rows against a host dot product
-    yh = y[:lm].cpu().numpy().astype(np.float64)
-    samp = np.unique(np.random.default_rng(1).integers(0, max(lm, 1), 2000)) if lm > 0 else np.array([], np.int64)
+def sampled_row_check(yh, rp, ci, va, x_host, np_dtype, col_map=None, count=2000):
+    """max over sampled rows of |y_i - sum_j a_ij x_j| / sum_j |a_ij x_j| against host dot products in fp64."""
+    lm = len(rp) - 1
+    samp = np.unique(np.random.default_rng(1).integers(0, max(lm, 1), count)) if lm > 0 else np.array([], np.int64)
     xg = x_host.astype(np.float64)
-    if world > 1:
-        own = np.repeat(np.arange(world), np.diff(offsets))
     max_rel = 0.0
-    rp, ci, va = blk["row_ptr"], blk["col_idx"], blk["values"]
     for i in samp:
         cols = ci[rp[i]:rp[i + 1]].astype(np.int64)
-        if world > 1 and layout == "padded":
-            p = cols // padded
-            cols = offsets[p] + (cols - p * padded)
+        if col_map is not None:
+            cols = col_map(cols)
         vals = va[rp[i]:rp[i + 1]].astype(np_dtype).astype(np.float64)
         ref = float(np.dot(vals, xg[cols]))
         den = float(np.dot(np.abs(vals), np.abs(xg[cols]))) or 1.0
-        max_rel = max(max_rel, abs(ref - yh[i]) / den)
-    tol = 1e-12 if dts == "f64" else 1e-5
-    if not (max_rel <= tol) or not np.all(yh[:lm] == yh[:lm]):
-        raise SystemExit(f"bench sanity check failed: sampled rows differ from the host dot products (max {max_rel})")
+        max_rel = max(max_rel, abs(ref - float(yh[i])) / den)
+    return max_rel, samp
 
-    # ------------------------------------------------------------------ report
-    gflops = 2.0 * nnz_total / (ms_per_step * 1e-3) / 1e9
-    B_alg = algorithmic_bytes(m, n, nnz_total, vbytes)
-    B_alg_local = algorithmic_bytes(lm, n_x if world == 1 else n, lnnz, vbytes)
-    ach = B_alg_local / (kernel_ms * 1e-3) / 1e9
-    ki = mats[0].kernel_info()
+
+def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_warm_seconds=0.0):
+    """Build one handle, run warm-up + `steps` back-to-back launches timed by HIP events on the launch stream, check sampled
+    rows. Returns a dict with the measured figures and leaves nothing on the device."""
+    np_dtype = np.float64 if dts == "f64" else np.float32
+    t_dtype = torch.float64 if dts == "f64" else torch.float32
+    vbytes = 8 if dts == "f64" else 4
+    m, n, nnz = A["m"], A["n"], A["nnz"]
+    if x_host is None:
+        x_host = np.random.default_rng(14).uniform(-1.0, 1.0, n).astype(np_dtype)
+    t0 = time.time()
+    M = E.Matrix(A["row_ptr"], A["col_idx"], A["values"], m, n, fmt, np_dtype, **opts)
+    t_conv = time.time() - t0
+    x = torch.from_numpy(x_host).cuda()
+    y = torch.full((m + 64,), 1.0, dtype=t_dtype, device="cuda")   # driver canary (bench_spmv.cpp:606-609)
+    sp = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        M.spmv_device(x.data_ptr(), y.data_ptr(), 0, sp)
+    torch.cuda.synchronize()
+    t_w = time.time()
+    while time.time() - t_w < min_warm_seconds:                  # small kernels: clocks and caches settle (the reference warms GPU kernels with 1000 calls)
+        M.time_device(x.data_ptr(), y.data_ptr(), max(steps, 20), sp)
+    t0 = time.perf_counter()
+    kernel_ms = M.time_device(x.data_ptr(), y.data_ptr(), steps, sp)   # HIP events on the launch stream
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / steps * 1e3
+    yh = y[:m].cpu().numpy().astype(np.float64)
+    max_rel, samp = sampled_row_check(yh, A["row_ptr"], A["col_idx"], A["values"], x_host, np_dtype)
+    tol = 1e-12 if dts == "f64" else 1e-5
+    if not (max_rel <= tol) or not np.all(yh == yh):
+        raise SystemExit(f"bench sanity check failed for {M.format_name}: sampled rows differ from the host dot products (max {max_rel})")
+    ki = M.kernel_info()
+    B = algorithmic_bytes(m, n, nnz, vbytes)
+    out = dict(format_name=M.format_name, kernel=ki["name"], kernel_ms=kernel_ms, wall_ms=wall_ms, convert_s=t_conv,
+               algorithmic_bytes=B, gbps=B / (kernel_ms * 1e-3) / 1e9, gflops=2.0 * nnz / (kernel_ms * 1e-3) / 1e9,
+               mem_footprint=M.mem_footprint, check=max_rel, yh=yh, samp=samp, x_host=x_host)
+    M.close()
+    del x, y
+    return out
+
+
+def roofline_record(workload, dts, t, with_traffic=True):
+    """The "roofline" object of one timed kernel."""
+    traffic = load_traffic(workload, t["format_name"], dts, t["kernel"]) if with_traffic else None
+    resident = t["algorithmic_bytes"] < INFINITY_CACHE_BYTES
+    frac = t["gbps"] / HBM_PEAK_GBPS
+    return {"bound": "hbm", "achieved": round(t["gbps"], 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(frac, 4),
+            "frac_algorithmic": round(frac, 4),
+            "frac_hbm_measured": None if traffic is None else round(traffic / (t["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "traffic": traffic, "kernel": t["kernel"], "kernel_ms": round(t["kernel_ms"], 6),
+            "algorithmic_bytes_per_launch": int(t["algorithmic_bytes"]),
+            # a working set under the 256 MiB Infinity Cache is served on-die when launched back to back: its GB/s is a cache
+            # rate, not an HBM rate (DESIGN §5)
+            "cache_resident": bool(resident)}
+
+
+def run_small_configs(E, torch, H, args):
+    """Configs 1-4 of BASELINE.json: the NAMED kernel and the engine's best kernel on each twin, a few hundred launches each."""
+    out = []
+    for w in SMALL_CONFIGS:
+        t0 = time.time()
+        A, data = load_workload(H, w, args.scale)
+        t_gen = time.time() - t0
+        dts = DEFAULT_DTYPE.get(w, "f64")
+        nf, no = NAMED_KERNEL[w]
+        bf, bo = DEFAULT_FORMAT[w], DEFAULT_OPTS.get(w, {})
+        steps = args.configs_steps if A["nnz"] < 20_000_000 else max(20, args.configs_steps // 6)
+        warm = 0.1 if A["nnz"] < 20_000_000 else 0.0
+        named = time_handle(E, torch, A, nf, dts, dict(no), steps, 20, min_warm_seconds=warm)
+        best = time_handle(E, torch, A, bf, dts, dict(bo), steps, 20, x_host=named["x_host"], min_warm_seconds=warm)
+        rn, rb = roofline_record(w, dts, named), roofline_record(w, dts, best)
+        out.append({"workload": f"{w} ({'synthetic twin' if data == 'synthetic' else data})", "dtype": dts,
+                    "rows": int(A["m"]), "nnz": int(A["nnz"]), "algorithmic_bytes": int(named["algorithmic_bytes"]),
+                    "cache_resident": rn["cache_resident"],
+                    "named_kernel": named["kernel"], "named_format": named["format_name"], "named_ms": round(named["kernel_ms"], 6),
+                    "named_gflops": round(named["gflops"], 2), "named_frac": rn["frac"], "named_traffic": rn["traffic"],
+                    "best_kernel": best["kernel"], "best_format": best["format_name"], "best_ms": round(best["kernel_ms"], 6),
+                    "best_gflops": round(best["gflops"], 2), "best_frac": rb["frac"], "traffic": rb["traffic"],
+                    "frac_hbm_measured": rb["frac_hbm_measured"],
+                    "check_max_err_over_abs_row": max(named["check"], best["check"]),
+                    "setup_s": round(t_gen + named["convert_s"] + best["convert_s"], 2)})
+        del A, named, best
+    return out
+
+
+def strided_sample(rp, ci, va, lm, max_nnz, chunks=64):
+    """An nnz-bounded sample of the matrix for the CPU baseline: `chunks` row ranges spread evenly over the whole matrix (each
+    holding 1/chunks of the budget), concatenated into one CSR over the full column space."""
+    lnnz = int(rp[lm])
+    if lnnz <= max_nnz:
+        return rp[:lm + 1], ci[:lnnz], va[:lnnz], np.arange(lm), f"whole matrix ({lnnz} nnz)"
+    per = max_nnz // chunks
+    rows = []
+    for c in range(chunks):
+        r0 = int(np.searchsorted(rp, int(lnnz * c / chunks), side="left"))
+        r0 = min(r0, lm)
+        r1 = int(np.searchsorted(rp, int(rp[r0]) + per, side="right")) - 1
+        r1 = max(r0, min(r1, lm))
+        if rows and r0 < rows[-1][1]:
+            r0 = rows[-1][1]
+        if r1 > r0:
+            rows.append((r0, r1))
+    srp = [np.zeros(1, np.int64)]
+    acc = 0
+    for r0, r1 in rows:
+        seg = rp[r0:r1 + 1].astype(np.int64)
+        srp.append(seg[1:] - seg[0] + acc)
+        acc += int(seg[-1] - seg[0])
+    srp = np.concatenate(srp).astype(np.int32)
+    sci = np.concatenate([ci[rp[r0]:rp[r1]] for r0, r1 in rows])
+    sva = np.concatenate([va[rp[r0]:rp[r1]] for r0, r1 in rows])
+    row_ids = np.concatenate([np.arange(r0, r1) for r0, r1 in rows])
+    return srp, sci, sva, row_ids, f"{len(rows)} row ranges spread evenly over the matrix ({len(row_ids)} rows, {acc} nnz)"
+
+
+def cpu_baseline(args, workload, dts, A, x_host, yh):
+    """The reference's CPU CSR backend (oracle/_ref, compiled in place from /root/reference by oracle/Makefile) timed on this
+    host's cores on a bounded sample of the same workload; falls back to the oracle's port of the same loop."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc                                  # checker only: timed beside the GPU, never shipped
+    # the GPU box shows every host CPU but one GPU's share is 16 cores (oversubscribing 256 threads is 10x slower)
+    cores = int(os.environ.get("SPMV_CPU_THREADS", min(cpu_share(), 16)))
+    rp, ci, va, lm, n = A["row_ptr"], A["col_idx"], A["values"], A["m"], A["n"]
+    srp, sci, sva, row_ids, sample = strided_sample(rp, ci, va, lm, 64_000_000)
+    rs, snnz = len(srp) - 1, int(srp[-1])
+    kind, tb, ys = "port", None, None
+    try:
+        import refdrv
+        flavour = "native" if refdrv.available("csr", "d", "native") else "v3"
+        prec = "f" if dts == "f32" else "d"
+        if refdrv.available("csr", prec, flavour):
+            with QuietStdout():                                   # the reference prints to C stdout; ours carries ONE JSON line
+                rb = refdrv.RefBackend("csr", prec, flavour, threads=cores)
+                rb.csr_to_format(srp, sci, sva, rs, n)
+                ys = rb.spmv(x_host).astype(np.float64)
+                tb = rb.time_spmv(x_host, min_loops=5, min_runtime=args.cpu_baseline_seconds)
+            kind = "reference"
+    except Exception as e:                                        # e.g. an AVX-512 build on a CPU without it
+        print(f"[bench] reference CPU backend unavailable ({e}); timing the oracle port", file=sys.stderr)
+        tb = None
+    if tb is None:
+        tb = orc.time_csr_spmv(srp, sci, sva, x_host.astype(np.float64), cores, min_loops=5, min_runtime=args.cpu_baseline_seconds)
+        ys = np.asarray(tb["y"], np.float64)
+    # the baseline must have done the work: its y agrees with the GPU's on the sampled rows
+    probe = np.unique(np.random.default_rng(2).integers(0, max(rs, 1), 2000))
+    if len(probe):
+        g = yh[row_ids[probe]]
+        dmax = float(np.max(np.abs(ys[probe] - g) / np.maximum(np.abs(g), 1e-300)))
+        assert dmax < 1e-9 or dts == "f32", f"CPU baseline result differs from the GPU result ({dmax})"
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "")
+    except OSError:
+        pass
+    vb = (4 if dts == "f32" else 8) if kind == "reference" else 8
+    touched = np.zeros(n, bool)
+    touched[sci] = True
+    x_read = int(touched.sum())
+    # bytes of the sample: its matrix stream, its row pointers, the x entries it actually reads, the y entries it writes
+    sbytes = snnz * (vb + 4) + (rs + 1) * 4 + (x_read + rs) * vb
+    return {"value": round(2.0 * snnz / tb["median"] / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "cpu_model": cpu_model,
+            "kind": kind, "sample": f"{sample} of {workload}", "median_s": tb["median"], "loops": tb["loops"],
+            "gbps": round(sbytes / tb["median"] / 1e9, 2), "sample_bytes": int(sbytes), "x_entries_read": x_read}
+
+
+def main():
+    args = parse()
+    # Host threads: the GPU box shows all 256 cores but a job owns a cgroup CPU quota (16 cores per GPU); an OpenMP team
+    # of 256 burns the quota in a few ms and the kernel then freezes the whole process — the thread feeding the GPU
+    # included — until the next 100 ms period (csrc/host_threads.hpp has the measurement). torch.distributed.run on the
+    # other hand pins OMP_NUM_THREADS=1. Either way: give every rank its share, before any OpenMP runtime starts.
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    share = max(1, min(cpu_share(), len(os.sched_getaffinity(0))) // int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    if "OMP_NUM_THREADS" not in os.environ or (world > 1 and os.environ["OMP_NUM_THREADS"] == "1"):
+        os.environ["OMP_NUM_THREADS"] = str(min(share, 16) if world > 1 else share)
+    os.environ.setdefault("KMP_BLOCKTIME", "0")
+    import torch
+    import spmv_host as H
+    import spmv_mi355x as E
+
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if world > 1:
+        import bench_multi
+        result = bench_multi.run(args, sys.modules[__name__])
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        return
+
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    workload = args.workload
+    fmt = args.format or DEFAULT_FORMAT.get(workload, "csr_vector")
+    dts = args.dtype or DEFAULT_DTYPE.get(workload, "f64")
+    opts = collect_opts(args, workload)
+
+    t0 = time.time()
+    A, data = load_workload(H, workload, args.scale, args.jitter, args.jitter_span)
+    t_gen = time.time() - t0
+    m, n, nnz = A["m"], A["n"], A["nnz"]
+    small = nnz < 20_000_000
+    t = time_handle(E, torch, A, fmt, dts, opts, args.steps, args.warmup, min_warm_seconds=0.25 if small else 0.0)
+    ms_per_step = t["wall_ms"]                    # barrier + synchronize bracket around exactly K launches
+    gflops = 2.0 * nnz / (ms_per_step * 1e-3) / 1e9
+    B_alg = t["algorithmic_bytes"]
+    wl = f"{workload} ({'synthetic twin' if data == 'synthetic' else data})" + ("" if args.scale == 1.0 else f" scale={args.scale}")
+    if args.jitter:
+        wl += f" jitter={args.jitter}x+-{args.jitter_span}"
     result = {
         "metric": f"GFLOP/s (2*nnz/t, {'fp64' if dts == 'f64' else 'fp32'} SpMV y=A*x); achieved HBM GB/s and % of peak in 'roofline'",
-        "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
         "scaling": "strong",            # total work (one SpMV of the whole matrix) is fixed as N grows
-        "vs_baseline": None, "dtype": dts, "data": "synthetic",
-        "config": {"workload": f"{workload} (synthetic twin)" + ("" if args.scale == 1.0 else f" scale={args.scale}"),
-                   "format": mats[0].format_name, "rows": int(m), "cols": int(n), "nnz": int(nnz_total),
-                   "parallelism": "single GPU" if world == 1 else
-                   f"row-partitioned x{world} ({'row blocks of A' if partition_info['kind'] == 'rows' else 'breadth-first slabs of the matrix graph, x in original numbering' if layout == 'original' else 'row blocks of P A P^T, P = breadth-first slabs'}), "
-                   f"RCCL {'packed halo ' + ('all_to_all' if packed.mode == 'alltoall' else 'send/recv') if layout == 'original' else 'send/recv of the needed x ranges' if use_p2p else 'allgather(x)'} "
-                   f"{('overlapped with the interior rows' if layout == 'original' else 'overlapped with local columns') if args.overlap else 'then SpMV'}"},
+        "vs_baseline": None, "dtype": dts, "data": "synthetic" if data == "synthetic" else data,
+        "config": {"workload": wl, "format": t["format_name"], "rows": int(m), "cols": int(n), "nnz": int(nnz),
+                   "parallelism": "single GPU", "stored_bytes_per_nnz": round(t["mem_footprint"] / max(nnz, 1), 3)},
         "hbm_gbps_algorithmic": round(B_alg / (ms_per_step * 1e-3) / 1e9, 2),
-        "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 2),
-        "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(ach / HBM_PEAK_GBPS, 4),
-                     "traffic": load_traffic(workload, fmt, dts, ki["name"]) if world == 1 and args.scale == 1.0 else None,
-                     "kernel": ki["name"], "kernel_ms": round(kernel_ms, 6),
-                     "algorithmic_bytes_per_launch": int(B_alg_local)},
-        "check_max_err_over_abs_row": max_rel,
-        "exchange": exchange_info,
-        "partition": partition_info,
-        "breakdown_ms": None if world == 1 else {"exchange_alone": round(comm_only_ms, 4), "kernels_alone": round(kernels_only_ms, 4),
-                                                 "overlap_efficiency": round((comm_only_ms + kernels_only_ms) / ms_per_step, 3)},
-        "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t_conv, 2)},
+        "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 2),
+        "roofline": roofline_record(workload, dts, t, with_traffic=args.scale == 1.0 and not args.jitter),
+        "check_max_err_over_abs_row": t["check"],
+        "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t["convert_s"], 2)},
     }
-
-    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1): reference build, else the port
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as orc                                  # checker only: timed beside the GPU, never shipped
-        # the GPU box shows every host CPU but one GPU's share is 16 cores (oversubscribing 256 threads is 10x slower)
-        cores = int(os.environ.get("SPMV_CPU_THREADS", min(cpu_share(), 16)))
-        max_nnz = 64_000_000
-        if lnnz > max_nnz:
-            rs = int(np.searchsorted(rp, max_nnz))
-            sample = f"first {rs} rows ({int(rp[rs])} nnz) of {workload}"
-        else:
-            rs = lm
-            sample = f"whole {workload} twin ({lnnz} nnz)"
-        snnz = int(rp[rs])
-        # Preferred baseline: the GENUINE reference CPU CSR backend (spmv_kernels/csr.cpp compiled in place by oracle/Makefile
-        # into oracle/_ref, which travels with the repo) under the reference driver's timing protocol; where that library
-        # is absent or does not load on this CPU, the oracle's port of the same path.
-        kind, tb, ys = "port", None, None
-        try:
-            import refdrv
-            flavour = "native" if refdrv.available("csr", "d", "native") else "v3"
-            prec = "f" if dts == "f32" else "d"
-            if refdrv.available("csr", prec, flavour):
-                with QuietStdout():                                   # the reference prints to C stdout; ours carries ONE JSON line
-                    rb = refdrv.RefBackend("csr", prec, flavour, threads=cores)
-                    rb.csr_to_format(rp[:rs + 1], ci[:snnz], va[:snnz], rs, n)
-                    ys = rb.spmv(x_host).astype(np.float64)
-                    tb = rb.time_spmv(x_host, min_loops=5, min_runtime=args.cpu_baseline_seconds)
-                kind = "reference"
-        except Exception as e:                                        # e.g. an AVX-512 build on a CPU without it
-            print(f"[bench] reference CPU backend unavailable ({e}); timing the oracle port", file=sys.stderr)
-            tb = None
-        if tb is None:
-            tb = orc.time_csr_spmv(rp[:rs + 1], ci[:snnz], va[:snnz], x_host.astype(np.float64), cores,
-                                   min_loops=5, min_runtime=args.cpu_baseline_seconds)
-            ys = np.asarray(tb["y"], np.float64)
-        # the baseline must have done the work: its y agrees with the GPU's on the sampled rows
-        chk = [i for i in samp if i < rs]
-        if chk:
-            dmax = float(np.max(np.abs(ys[chk] - yh[chk]) / np.maximum(np.abs(yh[chk]), 1e-300)))
-            assert dmax < 1e-9 or dts == "f32", f"CPU baseline result differs from the GPU result ({dmax})"
-        cpu_model = ""
-        try:
-            with open("/proc/cpuinfo") as fh:
-                cpu_model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "")
-        except OSError:
-            pass
-        result["cpu_baseline"] = {"value": round(2.0 * snnz / tb["median"] / 1e9, 3), "unit": "GFLOP/s",
-                                  "cores": cores, "cpu_model": cpu_model, "kind": kind, "sample": sample,
-                                  "median_s": tb["median"], "loops": tb["loops"],
-                                  "gbps": round(algorithmic_bytes(rs, n, snnz, (4 if dts == "f32" else 8) if kind == "reference" else 8) / tb["median"] / 1e9, 2)}
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, workload, dts, A, t["x_host"], t["yh"])
+    del A, t
+    want_configs = args.configs == "on" or (args.configs == "auto" and workload == "nlpkkt240" and args.format is None
+                                            and args.scale == 1.0 and not args.jitter)
+    if want_configs:
+        result["configs"] = run_small_configs(E, torch, H, args)
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -84,9 +84,11 @@ typedef struct {
 	                           y = (T + T^t - diag T) x. Expanded at create(); rows()/nnz() then report the expanded matrix */
 	int  rows_per_group;    /* CSR_VECTOR: consecutive rows a lane group keeps in flight together (1, 2 or 4; 2 and 4 need
 	                           lanes_per_row >= 8); 0 = auto                                                        */
-	int  col_blocks;        /* COO: 0 = row-sorted COO (the reference's layout); -1 = column-blocked COO for graph matrices with
-	                           blocks of ~384 KiB of x; > 0 = that many column blocks. Rows are cut into segments whose y lives in
-	                           LDS, entries are ordered by column block inside a segment (csrc/kernels_coo.hip)            */
+	int  col_blocks;        /* COO: 0 = row-sorted COO (the reference's layout); -1 = column-blocked layout for graph matrices with
+	                           blocks of ~384 KiB of x; > 0 = that many column blocks (at most 65 536 columns each). The rows are
+	                           dealt to workgroups that keep their y in LDS, the entries are ordered by column block (csrc/kernels_coo.hip).
+	                           CSR_MERGE: the same layout with merge-path-balanced row ranges: 0 = auto (taken when the x gathers
+	                           are scattered over a vector no L2 holds), -1 / > 0 = on, -2 = plain CSR-order merge path            */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */

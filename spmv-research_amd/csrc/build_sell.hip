@@ -1,0 +1,369 @@
+// csr_to_format() for SELL-C-sigma (sell_sorted.cpp:112-298, sell_c_s.cpp:39-77 + sell-C-s/RISC-V/sellcs_format.c:137-200):
+// the plain column-major layout (C = 16/32/64), the delta-compressed SELL-64 layout (host builder; the GPU builder is
+// convert_sell.hip) and the LDS-window layout for banded matrices (kernels_sell_window.hip).
+#include "handle.hpp"
+
+namespace spmv {
+
+// ---------------------------------------------------------------------------------------------------- SELL build
+// Host-side CSR -> SELL-C-sigma (the reference converts on the host too: sell_sorted.cpp:112-298, sellcs_format.c:137-200).
+// Window sort: stable, DESCENDING row length inside each window of sigma rows (radix_sort.c:103-122 semantics).
+static int
+build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va)
+{
+	const long m = A->m;
+	const int C = A->sell_c;
+	const int TPR = WAVE / C;
+	const long sigma = A->sell_sigma;
+	const long num_slices = (m + C - 1) / C;
+	std::vector<int> row_of_sorted(std::max<long>(m, 1));
+	const long num_windows = (m + sigma - 1) / sigma;
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4)
+	for (long w = 0; w < num_windows; w++)
+	{
+		long s = w * sigma, e = std::min(m, s + sigma);
+		// counting sort by length, descending, stable
+		int maxlen = 0;
+		for (long i = s; i < e; i++)
+			maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
+		std::vector<long> cnt((size_t) maxlen + 2, 0);
+		for (long i = s; i < e; i++)
+			cnt[maxlen - (rp[i + 1] - rp[i]) + 1]++;
+		for (int b = 0; b <= maxlen; b++)
+			cnt[b + 1] += cnt[b];
+		for (long i = s; i < e; i++)
+			row_of_sorted[s + cnt[maxlen - (rp[i + 1] - rp[i])]++] = (int) i;
+	}
+	std::vector<int64_t> slice_ptr((size_t) num_slices + 1, 0);
+	#pragma omp parallel for num_threads(spmv::host_threads())
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		long width = 0;
+		for (long i = sl * C; i < std::min(m, (sl + 1) * C); i++)
+		{
+			int o = row_of_sorted[i];
+			width = std::max<long>(width, rp[o + 1] - rp[o]);
+		}
+		width = (width + TPR - 1) / TPR * TPR;
+		slice_ptr[sl + 1] = width * C;
+	}
+	for (long sl = 0; sl < num_slices; sl++)
+		slice_ptr[sl + 1] += slice_ptr[sl];
+	const int64_t nnz_ext = slice_ptr[num_slices];
+	std::vector<int> col((size_t) std::max<int64_t>(nnz_ext, 1));
+	std::vector<double> val((size_t) std::max<int64_t>(nnz_ext, 1));
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 64)
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		const int64_t base = slice_ptr[sl];
+		const long width = (slice_ptr[sl + 1] - base) / C;
+		for (int r = 0; r < C; r++)
+		{
+			long i = sl * C + r;
+			long js = 0, len = 0;
+			if (i < m)
+			{
+				int o = row_of_sorted[i];
+				js = rp[o];
+				len = rp[o + 1] - rp[o];
+			}
+			// padding: value 0 times a column this row already touches (keeps the gather in cache; the reference pads
+			// with the last real column as well, sell_sorted.cpp:280-284)
+			int pad_col = len > 0 ? ci[js + len - 1] : 0;
+			for (long k = 0; k < width; k++)
+			{
+				int64_t p = base + k * C + r;
+				if (k < len)
+				{
+					col[p] = ci[js + k];
+					val[p] = va[js + k];
+				}
+				else
+				{
+					col[p] = pad_col;
+					val[p] = 0.0;
+				}
+			}
+		}
+	}
+	A->sell_slices = num_slices;
+	A->sell_nnz_ext = nnz_ext;
+	A->cfg.map = xcd_map_balanced(slice_ptr.data(), num_slices, sell_slices_per_tile(),
+			resolve_remap(A->remap, (num_slices + sell_slices_per_tile() - 1) / sell_slices_per_tile()));
+	if (dev_alloc(&A->d_slice_ptr, (size_t) num_slices + 1))
+		return 1;
+	HIP_TRY(hipMemcpy(A->d_slice_ptr, slice_ptr.data(), ((size_t) num_slices + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+	if (upload_ints(col.data(), (size_t) nnz_ext, &A->d_col))
+		return 1;
+	if (upload_values(A, val.data(), (size_t) nnz_ext, &A->d_val))
+		return 1;
+	if (upload_ints(row_of_sorted.data(), (size_t) m, &A->d_row_of_sorted))
+		return 1;
+	// (num_slices+1) offsets + padded entries + the row permutation (cf. sell_sorted.cpp:297)
+	A->mem_footprint = (double) (num_slices + 1) * sizeof(int64_t) + (double) nnz_ext * (A->vbytes + 4) + (double) m * 4;
+	return 0;
+}
+
+// SELL-64-sigma-delta build (layout: kernels_sell.hip). Same sigma-window sort and slice widths as build_sell with C = 64,
+// widths padded to a multiple of 4 steps; per slice the narrowest index encoding that holds every (step, lane) delta.
+static int
+build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va)
+{
+	const long m = A->m;
+	constexpr int C = 64;
+	const long sigma = A->sell_sigma;
+	const long num_slices = (m + C - 1) / C;
+	if (A->convert_on_device)
+	{
+		std::vector<int64_t> val_ptr;
+		int64_t nnz_ext = 0, idx_bytes = 0;
+		void * d_val = nullptr;
+		if (sell_delta_convert_device(A->f32, m, A->n, A->nnz, sigma, rp, ci, va, &A->d_row_of_sorted, &A->d_sell_desc, &A->d_sell_idx,
+				&d_val, val_ptr, A->sell_mode_slices, &nnz_ext, &idx_bytes))
+			return 1;
+		A->d_val = d_val;
+		A->sell_slices = num_slices;
+		A->sell_nnz_ext = nnz_ext;
+		A->sell_idx_bytes = idx_bytes;
+		const long spt = sell_slices_per_tile() / A->sell_split;
+		A->cfg.map = xcd_map_balanced(val_ptr.data(), num_slices, spt, resolve_remap(A->remap, (num_slices + spt - 1) / spt));
+		A->mem_footprint = (double) (num_slices + 1) * 16 + (double) nnz_ext * A->vbytes + (double) idx_bytes + (double) m * 4;
+		return 0;
+	}
+	std::vector<int> row_of_sorted(std::max<long>(m, 1));
+	const long num_windows = (m + sigma - 1) / sigma;
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4)
+	for (long w = 0; w < num_windows; w++)
+	{
+		long s = w * sigma, e = std::min(m, s + sigma);
+		int maxlen = 0;
+		for (long i = s; i < e; i++)
+			maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
+		std::vector<long> cnt((size_t) maxlen + 2, 0);
+		for (long i = s; i < e; i++)
+			cnt[maxlen - (rp[i + 1] - rp[i]) + 1]++;
+		for (int b = 0; b <= maxlen; b++)
+			cnt[b + 1] += cnt[b];
+		for (long i = s; i < e; i++)
+			row_of_sorted[s + cnt[maxlen - (rp[i + 1] - rp[i])]++] = (int) i;
+	}
+	// pass 1: width and mode of every slice
+	std::vector<int64_t> val_ptr((size_t) num_slices + 1, 0), idx_ptr((size_t) num_slices + 1, 0);
+	std::vector<unsigned char> mode((size_t) std::max<long>(num_slices, 1), 4);
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 64)
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		long width = 0;
+		const long i_e = std::min(m, (sl + 1) * C);
+		for (long i = sl * C; i < i_e; i++)
+		{
+			int o = row_of_sorted[i];
+			width = std::max<long>(width, rp[o + 1] - rp[o]);
+		}
+		const long maxlen = width;
+		width = (width + 3) / 4 * 4;
+		long maxdelta = 0;
+		// step-invariant lane offsets: a full slice of equally long rows whose step-k columns are c_k[lane 0] + off[lane] with the
+		// SAME off for every step (rows of one kind of a stencil: column = row + const_k). off = lane is the affine case.
+		bool rowoff = (sl + 1) * C <= m && A->n >= C && maxlen > 0;
+		for (long i = sl * C; i < i_e && rowoff; i++)
+		{
+			int o = row_of_sorted[i];
+			rowoff = (rp[o + 1] - rp[o]) == maxlen;
+		}
+		bool affine = (sl + 1) * C <= m && A->n >= C && maxlen == 0;      // an all-empty slice stores nothing either
+		if (rowoff)
+		{
+			const int o0 = row_of_sorted[sl * C];
+			affine = true;
+			for (long i = sl * C; i < i_e && rowoff; i++)
+			{
+				const int o = row_of_sorted[i];
+				const int off = ci[rp[o]] - ci[rp[o0]];
+				if (off != (int) (i - sl * C))
+					affine = false;
+				for (long k = 1; k < maxlen && rowoff; k++)
+					rowoff = ci[rp[o] + k] - ci[rp[o0] + k] == off;
+			}
+			if (!rowoff)
+				affine = false;
+		}
+		for (long k = 0; k < width; k++)
+		{
+			int lo = 0x7fffffff, hi = -1;
+			for (long i = sl * C; i < i_e; i++)
+			{
+				int o = row_of_sorted[i];
+				if (k < rp[o + 1] - rp[o])
+				{
+					int c = ci[rp[o] + k];
+					lo = std::min(lo, c);
+					hi = std::max(hi, c);
+				}
+			}
+			if (hi >= 0)
+				maxdelta = std::max<long>(maxdelta, (long) hi - lo);
+		}
+		const int md = affine ? 0 : rowoff ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		mode[sl] = (unsigned char) md;
+		val_ptr[sl + 1] = maxlen * C;                    // values: exact width; index groups: rounded up to 4 steps
+		idx_ptr[sl + 1] = (md == 3 ? 4 * C : 0) + (width / 4) * ((md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024);
+	}
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		val_ptr[sl + 1] += val_ptr[sl];
+		idx_ptr[sl + 1] += idx_ptr[sl];
+		A->sell_mode_slices[(mode[sl] == 0 || mode[sl] == 3) ? 3 : mode[sl] == 1 ? 0 : mode[sl] == 2 ? 1 : 2]++;
+	}
+	const int64_t nnz_ext = val_ptr[num_slices];
+	const int64_t idx_bytes = idx_ptr[num_slices];
+	std::vector<double> val((size_t) std::max<int64_t>(nnz_ext, 1));
+	std::vector<unsigned char> idx((size_t) std::max<int64_t>(idx_bytes, 16) + 1024, 0);
+	std::vector<int64_t> desc(2 * ((size_t) num_slices + 1), 0);
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 64)
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		const int64_t vb = val_ptr[sl];
+		const long maxlen = (val_ptr[sl + 1] - vb) / C;
+		const long width = (maxlen + 3) / 4 * 4;
+		const int md = mode[sl];
+		unsigned char * ib = idx.data() + idx_ptr[sl];
+		desc[2 * sl] = vb;
+		desc[2 * sl + 1] = idx_ptr[sl] | md;
+		const long i_e = std::min(m, (sl + 1) * C);
+		int min_off = 0;
+		if (md == 3)
+		{
+			// header: the 64 lane offsets (relative to lane 0's column), then the groups of 4 bases
+			const int o0 = row_of_sorted[sl * C];
+			for (int r = 0; r < C; r++)
+			{
+				const int off = ci[rp[row_of_sorted[sl * C + r]]] - ci[rp[o0]];
+				reinterpret_cast<int *>(ib)[r] = off;
+				min_off = std::min(min_off, off);
+			}
+			ib += 4 * C;
+		}
+		for (long k = 0; k < width; k++)
+		{
+			int base = 0x7fffffff;
+			for (long i = sl * C; i < i_e; i++)
+			{
+				int o = row_of_sorted[i];
+				if (k < rp[o + 1] - rp[o])
+					base = std::min(base, ci[rp[o] + k]);
+			}
+			if (base == 0x7fffffff)
+				base = 0;                              // a step that is padding for every lane
+			if (md == 3)                               // base + off[lane] must be lane 0's column (real step) / a valid column (padding)
+				base = (k < rp[row_of_sorted[sl * C] + 1] - rp[row_of_sorted[sl * C]]) ? ci[rp[row_of_sorted[sl * C]] + k] : -min_off;
+			const long g = k / 4, u = k % 4;
+			const long gbytes = (md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
+			unsigned char * gp = ib + g * gbytes;
+			if (md != 4)
+				reinterpret_cast<int *>(gp)[u] = base;
+			for (int r = 0; r < C; r++)
+			{
+				const long i = sl * C + r;
+				double v = 0.0;
+				int c = base;                              // padding: value 0 times a column some lane really uses
+				if (i < m)
+				{
+					int o = row_of_sorted[i];
+					if (k < rp[o + 1] - rp[o])
+					{
+						c = ci[rp[o] + k];
+						v = va[rp[o] + k];
+					}
+				}
+				if (k < maxlen)
+					val[vb + k * C + r] = v;                   // steps past the longest row exist in the index groups only
+				const unsigned d = (unsigned) (c - base);
+				if (md == 0 || md == 3)
+					continue;                                  // column = base + lane offset, nothing stored per lane and step
+				if (md == 1)
+					gp[16 + r * 4 + u] = (unsigned char) d;
+				else if (md == 2)
+					reinterpret_cast<unsigned short *>(gp + 16)[r * 4 + u] = (unsigned short) d;
+				else
+					reinterpret_cast<int *>(gp)[u * C + r] = c;
+			}
+		}
+	}
+	desc[2 * num_slices] = nnz_ext;
+	desc[2 * num_slices + 1] = idx_bytes | 4;
+	A->sell_slices = num_slices;
+	A->sell_nnz_ext = nnz_ext;
+	A->sell_idx_bytes = idx_bytes;
+	{
+		const long spt = sell_slices_per_tile() / A->sell_split;       // slices per workgroup
+		A->cfg.map = xcd_map_balanced(val_ptr.data(), num_slices, spt, resolve_remap(A->remap, (num_slices + spt - 1) / spt));
+	}
+	if (dev_alloc(&A->d_sell_desc, desc.size()))
+		return 1;
+	HIP_TRY(hipMemcpy(A->d_sell_desc, desc.data(), desc.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+	if (dev_alloc(&A->d_sell_idx, idx.size()))
+		return 1;
+	HIP_TRY(hipMemcpy(A->d_sell_idx, idx.data(), idx.size(), hipMemcpyHostToDevice));
+	if (upload_values(A, val.data(), (size_t) nnz_ext, &A->d_val))
+		return 1;
+	if (upload_ints(row_of_sorted.data(), (size_t) m, &A->d_row_of_sorted))
+		return 1;
+	A->mem_footprint = (double) (num_slices + 1) * 16 + (double) nnz_ext * A->vbytes + (double) idx_bytes + (double) m * 4;
+	return 0;
+}
+
+int
+build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * rp, const int * ci, const double * va)
+{
+	const long lm = A->m;
+	const char * pf = A->f32 ? "f" : "d";
+	int rc = 0;
+	// auto: one row per lane (C = 64, bit-exact) when there are enough slices to fill the chip several times over,
+	// else 16-row slices with 4 lanes per row (4x the wavefronts, 1/4 of the dependent chain) — profiles/sweep_r01.md
+	int C = o.sell_c ? o.sell_c : 64;
+	if (C != 16 && C != 32 && C != 64)
+	{
+		set_error("sell_c must be 16, 32 or 64 (got %d)", C);
+		rc = 1;
+		return 1;
+	}
+	long sigma = o.sell_sigma ? o.sell_sigma : 16384;
+	if (sigma < C || sigma % C)
+	{
+		set_error("sell_sigma (%ld) must be a positive multiple of sell_c (%d)", sigma, C);
+		rc = 1;
+		return 1;
+	}
+	A->sell_c = C;
+	A->sell_sigma = sigma;
+	A->sell_delta = (C == 64) && (o.sell_delta != 2);      // 0 = auto (on for 64-row slices), 1 = on, 2 = off
+	A->convert_on_device = o.convert_on != 2 && !getenv("SPMV_MI355X_HOST_CONVERT");
+	{
+		// waves per slice: enough wavefronts to occupy 256 CUs several times over
+		const long slices = (lm + 63) / 64;
+		int S = o.sell_split ? o.sell_split : (slices >= 16384 ? 1 : slices >= 8192 ? 2 : 4);
+		if (S != 1 && S != 2 && S != 4)
+		{
+			set_error("sell_split must be 1, 2 or 4 (got %d)", S);
+			rc = 1;
+			return 1;
+		}
+		A->sell_split = A->sell_delta ? S : 1;
+	}
+	if (o.sell_delta == 1 && C != 64)
+	{
+		set_error("sell_delta needs sell_c = 64 (one lane per row)");
+		rc = 1;
+		return 1;
+	}
+	rc = A->sell_delta ? build_sell_delta(A, rp, ci, va) : build_sell(A, rp, ci, va);
+	if (A->sell_delta && A->sell_split > 1)
+		snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELLD_%d_%ld_w%d_%s", C, sigma, A->sell_split, pf);
+	else
+		snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELL%s_%d_%ld_%s", A->sell_delta ? "D" : "", C, sigma, pf);
+	snprintf(A->kernel_name, sizeof(A->kernel_name), A->sell_delta ? "sell_delta_kernel" : "sell_kernel");
+	return rc;
+}
+
+}  // namespace spmv

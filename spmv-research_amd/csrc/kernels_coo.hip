@@ -187,123 +187,202 @@ launch_coo(bool f32, int items_per_lane, const int * rowind, const int * col, co
 // ------------------------------------------------------------------------------------------------ column-blocked COO
 //
 // For graph matrices (soc-LiveJournal1: 14 entries per row scattered over a 39 MB x) the row-sorted kernels sit on the
-// fabric's random-sector rate: every gather misses the 4 MiB L2 of its XCD. Here the rows are cut into segments of at most
-// COOB_ROWS rows (their y lives in LDS), 512 segments run at a time — all resident, two workgroups per CU — and every
-// workgroup walks ITS entries column block by column block (blocks of ~384 KiB of x, a barrier of the workgroup after every block), adding v*x[col] into the LDS copy of y
-// with LDS atomics. Segments hold equal numbers of entries, so the workgroups sweep the column blocks in step and the block
-// of x being gathered stays in every XCD's L2. Entry = (column: 4 B, row inside the segment: 2 B, value unless all values
-// are equal). The LDS atomics make the order of a row's additions run-dependent (last-bit differences; bar 1e-12 / 1e-5).
-constexpr int COOB_THREADS = 512;
-constexpr int COOB_U = 4;
-constexpr int COOB_SYNC_EVERY = 1;
+// fabric's random-sector rate: every gather misses the 4 MiB L2 of its XCD and most of the 64 bytes it brings are unused.
+// MI355X has 160 KiB of LDS on each of its 256 CUs — 40 MiB in all, as much as the whole y of such a matrix — and eight L2s
+// that each serve 32 CUs. The layout below is built around both:
+//   * the rows are cut into 8*P contiguous RANGES (P = 1 while y fits the chip's LDS); XCD k owns ranges k*P .. k*P+P-1 and
+//     works through them one after the other;
+//   * a range is dealt to 32 workgroups (one per CU, 1024 threads) in chunks of 16 rows, round-robin: every workgroup of the
+//     range sees the same column structure and the same number of entries per column block, and its y rows (<= 160 KiB)
+//     live in LDS for the whole launch, written back once as full 128-byte lines;
+//   * a workgroup's entries are ordered by column block (<= 65 536 columns of x, default 384 KiB) and, inside a block, by
+//     column: the 32 workgroups of an XCD sweep the same block at the same time, so the block is fetched into that L2 once,
+//     and neighbouring lanes gather from neighbouring lines (several entries per 128-byte line instead of one);
+//   * an entry is ONE dword: column inside the block (16 bits) | row inside the workgroup (16 bits), + the value unless all
+//     values are equal (Matrix-Market `pattern` matrices): 4 bytes per non-zero of stream instead of CSR's 12;
+//   * v*x[col] is added into the LDS copy of y with ds_add (LDS atomics): the order of a row's additions is run-dependent,
+//     parity is to the tolerance (1e-12 / 1e-5), not bit-wise.
+//   * a row too long for one workgroup's share (a hub of a power-law graph) is SPLIT over the 32 workgroups of its range, each
+//     summing a contiguous piece into an extra LDS slot; the 32 partial sums go to a carry array and a fix-up kernel adds
+//     them to y in workgroup order — the merge-path remedy (merge.cpp:302-318: partial rows + carry fix-up) inside this layout.
+// The next block's first batch of entries is in flight while the current block is consumed; a workgroup barrier after
+// every block keeps the 16 waves on the same block of x.
+constexpr int COOB_THREADS = 1024;
+constexpr int COOB_U = 8;                  // entries per lane and batch
+constexpr int COOB_WGS = 32;               // workgroups per range = CUs per XCD
+constexpr int COOB_CHUNK = 16;             // rows per chunk of the round-robin deal
+
+template <typename T, bool UNIT>
+struct CoobBatch {
+	unsigned e[COOB_U];
+	T v[UNIT ? 1 : COOB_U];
+};
+
+template <typename T, bool UNIT>
+__device__ __forceinline__ void
+coob_load(CoobBatch<T, UNIT> & b, const unsigned * __restrict__ ent, const T * __restrict__ val, int first, int end)
+{
+	#pragma unroll
+	for (int u = 0; u < COOB_U; u++)
+	{
+		const int ee = first + u * COOB_THREADS;
+		const bool ok = ee < end;
+		// the entry streams are read once: nontemporal, so that they do not push the x block out of L2
+		b.e[u] = ok ? ld_stream<true>(ent + ee) : 0u;
+		if constexpr (!UNIT)
+			b.v[u] = ok ? ld_stream<true>(val + ee) : (T) 0;
+	}
+}
+
+template <typename T, bool UNIT>
+__device__ __forceinline__ void
+coob_consume(const CoobBatch<T, UNIT> & b, const T * __restrict__ xb, T * __restrict__ ys, T unit, int first, int end)
+{
+	T xv[COOB_U];
+	#pragma unroll
+	for (int u = 0; u < COOB_U; u++)
+		xv[u] = (first + u * COOB_THREADS < end) ? xb[b.e[u] >> 16] : (T) 0;
+	#pragma unroll
+	for (int u = 0; u < COOB_U; u++)
+		if (first + u * COOB_THREADS < end)
+			unsafeAtomicAdd(&ys[b.e[u] & 0xffffu], (UNIT ? unit : b.v[u]) * xv[u]);
+}
 
 template <typename T, bool UNIT>
 __global__ __launch_bounds__(COOB_THREADS) void
-coo_blocked_kernel(const int * __restrict__ seg_row, const int * __restrict__ seg_blk, const int * __restrict__ col,
-		const unsigned short * __restrict__ lrow, const T * __restrict__ val, const T * __restrict__ x, T * __restrict__ y,
-		int seg_base, int num_segs, int num_blocks, T unit, int beta)
+coo_blocked_kernel(const int * __restrict__ wg_rows, const int * __restrict__ range_row, const int * __restrict__ seg_blk,
+		const int * __restrict__ range_blk, const int * __restrict__ range_long, const unsigned * __restrict__ ent,
+		const T * __restrict__ val, const T * __restrict__ x, T * __restrict__ y, T * __restrict__ carry,
+		int ranges_per_xcd, int num_blocks, int block_cols, T unit, int beta)
 {
 	extern __shared__ __align__(16) unsigned char coob_smem[];
 	T * ys = reinterpret_cast<T *>(coob_smem);
-	const int seg = seg_base + (int) blockIdx.x;
-	if (seg >= num_segs)
-		return;
-	const int r0 = seg_row[seg], nrows = seg_row[seg + 1] - r0;
-	for (int i = threadIdx.x; i < nrows; i += COOB_THREADS)
-		ys[i] = 0;
+	// workgroups are dealt round-robin to the XCDs: the i-th workgroup of XCD k is the (i % 32)-th of its (i / 32)-th range
+	const int xcd = (int) blockIdx.x % NUM_XCD;
+	const int i = (int) blockIdx.x / NUM_XCD;
+	const int range = xcd * ranges_per_xcd + i / COOB_WGS;
+	const int j = i % COOB_WGS;
+	const int t = range * COOB_WGS + j;
+	const int nloc = wg_rows[t];
+	if (nloc == 0)
+		return;                            // whole workgroup: no rows, hence no entries
+	const int tid = (int) threadIdx.x;
+	for (int l = tid; l < nloc; l += COOB_THREADS)
+		ys[l] = 0;
+	const int * sb = seg_blk + (size_t) t * (num_blocks + 1);
+	const int b0 = range_blk[2 * range], b1 = range_blk[2 * range + 1];
+	CoobBatch<T, UNIT> cur, nxt;
+	int e0 = b0 < b1 ? sb[b0] : 0, e1 = b0 < b1 ? sb[b0 + 1] : 0;
+	coob_load<T, UNIT>(cur, ent, val, e0 + tid, e1);
 	__syncthreads();
-	// block by block: measured faster than one flat walk over the segment's entries with 8 in flight (561 vs 589 us on the
-	// soc-LiveJournal1 twin) — the per-block loop is what keeps the workgroups on the same block of x
-	const int * sb = seg_blk + (size_t) seg * (num_blocks + 1);
-	for (int b = 0; b < num_blocks; b++)
+	for (int b = b0; b < b1; b++)
 	{
-		const int e1 = sb[b + 1];
-		for (int e = sb[b] + (int) threadIdx.x; e < e1; e += COOB_U * COOB_THREADS)
+		const int n1 = b + 1 < b1 ? sb[b + 2] : e1;      // next block: [e1, n1)
+		coob_load<T, UNIT>(nxt, ent, val, e1 + tid, n1);
+		const T * xb = x + (size_t) b * block_cols;
+		coob_consume<T, UNIT>(cur, xb, ys, unit, e0 + tid, e1);
+		for (int e = e0 + tid + COOB_U * COOB_THREADS; e < e1; e += COOB_U * COOB_THREADS)
 		{
-			int c[COOB_U];
-			unsigned short r[COOB_U];
-			T v[COOB_U];
-			#pragma unroll
-			for (int u = 0; u < COOB_U; u++)
-			{
-				const int ee = e + u * COOB_THREADS;
-				const bool ok = ee < e1;
-				// the entry streams are read once: nontemporal, so that they do not push the x block out of L2
-				c[u] = ok ? ld_stream<true>(col + ee) : -1;
-				r[u] = ok ? ld_stream<true>(lrow + ee) : (unsigned short) 0;
-				v[u] = UNIT ? unit : (ok ? ld_stream<true>(val + ee) : (T) 0);
-			}
-			T xv[COOB_U];
-			#pragma unroll
-			for (int u = 0; u < COOB_U; u++)
-				xv[u] = c[u] >= 0 ? x[c[u]] : (T) 0;
-			#pragma unroll
-			for (int u = 0; u < COOB_U; u++)
-				if (c[u] >= 0)
-					unsafeAtomicAdd(&ys[r[u]], v[u] * xv[u]);
+			CoobBatch<T, UNIT> more;
+			coob_load<T, UNIT>(more, ent, val, e, e1);
+			coob_consume<T, UNIT>(more, xb, ys, unit, e, e1);
 		}
-		if (COOB_SYNC_EVERY > 0 && (b + 1) % COOB_SYNC_EVERY == 0)
-			__syncthreads();                 // keep the waves of the workgroup on the same column block
+		__syncthreads();                     // keep the waves of the workgroup on the same column block
+		cur = nxt;
+		e0 = e1;
+		e1 = n1;
 	}
-	__syncthreads();
-	for (int i = threadIdx.x; i < nrows; i += COOB_THREADS)
-		y[r0 + i] = beta ? y[r0 + i] + ys[i] : ys[i];
+	// local row l = chunk (l / 16) of this workgroup, row l % 16 of the chunk; its chunks are j, j + 32, j + 64, ... of the range
+	const int r0 = range_row[range], r1 = range_row[range + 1];
+	const int k0 = range_long[range], nlong = range_long[range + 1] - k0;     // split rows of this range: the last `nlong` LDS slots
+	const int nnorm = nloc - nlong;
+	for (int l = tid; l < nnorm; l += COOB_THREADS)
+	{
+		const int row = r0 + ((l / COOB_CHUNK) * COOB_WGS + j) * COOB_CHUNK + l % COOB_CHUNK;
+		if (row < r1)
+			y[row] = beta ? y[row] + ys[l] : ys[l];
+	}
+	if (tid < nlong)
+		carry[(size_t) (k0 + tid) * COOB_WGS + j] = ys[nnorm + tid];
 }
+
+// adds the 32 partial sums of every split row to y, in workgroup order (deterministic given the partial sums)
+template <typename T>
+__global__ __launch_bounds__(256) void
+coo_blocked_fixup_kernel(const int * __restrict__ long_row, const T * __restrict__ carry, int num_long, T * __restrict__ y)
+{
+	const int k = (int) (blockIdx.x * 256 + threadIdx.x);
+	if (k >= num_long)
+		return;
+	T sum = 0;
+	for (int j = 0; j < COOB_WGS; j++)
+		sum += carry[(size_t) k * COOB_WGS + j];
+	y[long_row[k]] += sum;
+}
+
+int coo_blocked_wgs_per_range() { return COOB_WGS; }
+int coo_blocked_chunk_rows() { return COOB_CHUNK; }
+int coo_blocked_max_long_rows() { return 64; }     // split rows per range (LDS slots set aside in every workgroup)
 
 int
 coo_blocked_rows_cap(bool f32)
 {
-	static const int rows = [] {
-		const char * e = getenv("SPMV_MI355X_COOB_ROWS");             // experiments only
-		return e && atoi(e) >= 256 && atoi(e) <= 16384 ? atoi(e) : 8192;
-	}();
-	return f32 ? 2 * rows : rows;      // default 64 KiB of LDS per workgroup: two workgroups per CU
-}
-
-int
-coo_blocked_segments_per_launch()
-{
-	// as many as are resident together (160 KiB of LDS per CU, 256 CUs), so that everything launched sweeps in step
-	const int per_cu = std::max(1, std::min(4, (160 * 1024) / (coo_blocked_rows_cap(false) * 8 + 1024)));
-	return 256 * per_cu;
+	// rows of y one workgroup keeps in LDS: the CU's 160 KiB less a little for the runtime, at most what 16 bits index
+	const int bytes = 160 * 1024 - 512;
+	int rows = bytes / (f32 ? 4 : 8) / COOB_CHUNK * COOB_CHUNK;
+	if (const char * e = getenv("SPMV_MI355X_COOB_ROWS"))          // tests: a small cap makes small matrices take several passes
+		if (atoi(e) >= COOB_CHUNK && atoi(e) <= rows)
+			rows = atoi(e) / COOB_CHUNK * COOB_CHUNK + coo_blocked_max_long_rows();
+	return std::min(rows, 65536 / COOB_CHUNK * COOB_CHUNK - COOB_CHUNK) - coo_blocked_max_long_rows();
 }
 
 template <typename T>
 static int
-coo_blocked_launch(const int * seg_row, const int * seg_blk, const int * col, const unsigned short * lrow, const void * val,
-		const void * x, void * y, int num_segs, int num_blocks, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+coo_blocked_launch(const int * wg_rows, const int * range_row, const int * seg_blk, const int * range_blk, const int * range_long,
+		const int * long_row, int num_long, const unsigned * ent, const void * val, const void * x, void * y, void * carry, int num_ranges,
+		int num_blocks, int block_cols, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
-	static int granted = 0;
-	if (lds_bytes > granted)
+	// more than 64 KiB of dynamic LDS has to be granted per kernel function, once per device
+	static int granted[64] = {0};
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	if (dev >= 0 && dev < 64 && lds_bytes > granted[dev])
 	{
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&coo_blocked_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&coo_blocked_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-		granted = lds_bytes;
+		granted[dev] = lds_bytes;
 	}
-	const int per = coo_blocked_segments_per_launch();
+	const unsigned grid = (unsigned) num_ranges * COOB_WGS;
 	if (grid_out)
-		*grid_out = std::min(num_segs, per);
-	for (int base = 0; base < num_segs; base += per)
-	{
-		const unsigned grid = (unsigned) std::min(per, num_segs - base);
-		if (cfg.unit)
-			hipLaunchKernelGGL((coo_blocked_kernel<T, true>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, seg_row, seg_blk, col, lrow,
-					(const T *) nullptr, (const T *) x, (T *) y, base, num_segs, num_blocks, (T) cfg.unit_value, cfg.beta);
-		else
-			hipLaunchKernelGGL((coo_blocked_kernel<T, false>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, seg_row, seg_blk, col, lrow,
-					(const T *) val, (const T *) x, (T *) y, base, num_segs, num_blocks, (T) 0, cfg.beta);
-	}
+		*grid_out = grid;
+	if (grid == 0)
+		return 0;
+	const int per_xcd = num_ranges / NUM_XCD;
+	if (cfg.unit)
+		hipLaunchKernelGGL((coo_blocked_kernel<T, true>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, wg_rows, range_row, seg_blk, range_blk,
+				range_long, ent, (const T *) nullptr, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, block_cols, (T) cfg.unit_value, cfg.beta);
+	else
+		hipLaunchKernelGGL((coo_blocked_kernel<T, false>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, wg_rows, range_row, seg_blk, range_blk,
+				range_long, ent, (const T *) val, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, block_cols, (T) 0, cfg.beta);
 	HIP_TRY(hipGetLastError());
+	if (num_long > 0)
+	{
+		hipLaunchKernelGGL((coo_blocked_fixup_kernel<T>), dim3((unsigned) ((num_long + 255) / 256)), dim3(256), 0, stream, long_row, (const T *) carry,
+				num_long, (T *) y);
+		HIP_TRY(hipGetLastError());
+	}
 	return 0;
 }
 
 int
-launch_coo_blocked(bool f32, const int * seg_row, const int * seg_blk, const int * col, const unsigned short * lrow, const void * val,
-		const void * x, void * y, int num_segs, int num_blocks, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+launch_coo_blocked(bool f32, const int * wg_rows, const int * range_row, const int * seg_blk, const int * range_blk, const int * range_long,
+		const int * long_row, int num_long, const unsigned * ent, const void * val, const void * x, void * y, void * carry, int num_ranges,
+		int num_blocks, int block_cols, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
-	return f32 ? coo_blocked_launch<float>(seg_row, seg_blk, col, lrow, val, x, y, num_segs, num_blocks, lds_bytes, cfg, stream, grid_out)
-	           : coo_blocked_launch<double>(seg_row, seg_blk, col, lrow, val, x, y, num_segs, num_blocks, lds_bytes, cfg, stream, grid_out);
+	return f32 ? coo_blocked_launch<float>(wg_rows, range_row, seg_blk, range_blk, range_long, long_row, num_long, ent, val, x, y, carry, num_ranges,
+	                                       num_blocks, block_cols, lds_bytes, cfg, stream, grid_out)
+	           : coo_blocked_launch<double>(wg_rows, range_row, seg_blk, range_blk, range_long, long_row, num_long, ent, val, x, y, carry, num_ranges,
+	                                        num_blocks, block_cols, lds_bytes, cfg, stream, grid_out);
 }
 
 }  // namespace spmv
-

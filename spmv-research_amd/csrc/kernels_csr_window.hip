@@ -263,9 +263,12 @@ csr_window_launch(const int * row_ptr, const void * col_v, const void * val, con
 		*grid_out = grid;
 	if (grid == 0)
 		return 0;
-	// more than 64 KiB of dynamic LDS has to be granted per kernel function, once
-	static int granted_nt = 0, granted = 0;
-	int & have = cfg.nt ? granted_nt : granted;
+	// more than 64 KiB of dynamic LDS has to be granted per kernel function, once per device
+	static int granted_nt[64] = {0}, granted[64] = {0};
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	dev = dev < 0 || dev >= 64 ? 0 : dev;
+	int & have = cfg.nt ? granted_nt[dev] : granted[dev];
 	if (lds_bytes > have)
 	{
 		if (cfg.nt)

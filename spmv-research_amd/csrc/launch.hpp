@@ -77,11 +77,14 @@ int launch_coo(bool f32, int items_per_lane, const int * rowind, const int * col
 		int m, long nnz, int num_waves, int * carry_row, void * carry_val,
 		const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
-// column-blocked COO for graph matrices: segments of rows with their y in LDS, entries ordered by column block inside a segment
-int coo_blocked_rows_cap(bool f32);
-int coo_blocked_segments_per_launch();
-int launch_coo_blocked(bool f32, const int * seg_row, const int * seg_blk, const int * col, const unsigned short * lrow, const void * val,
-		const void * x, void * y, int num_segs, int num_blocks, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+// column-blocked COO for graph matrices: y of a workgroup's rows in LDS, entries ordered by column block, one dword per entry
+int coo_blocked_rows_cap(bool f32);                                    // rows of y one workgroup can keep in LDS
+int coo_blocked_wgs_per_range();                                       // workgroups a row range is dealt to (32 = CUs per XCD)
+int coo_blocked_chunk_rows();                                          // rows per chunk of that round-robin deal (16)
+int coo_blocked_max_long_rows();                                       // rows per range that may be split over its workgroups
+int launch_coo_blocked(bool f32, const int * wg_rows, const int * range_row, const int * seg_blk, const int * range_blk, const int * range_long,
+		const int * long_row, int num_long, const unsigned * ent, const void * val, const void * x, void * y, void * carry, int num_ranges,
+		int num_blocks, int block_cols, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
 // ---- small utility kernels (kernels_csr.hip)
 int launch_expand_rows(const int * row_ptr, int m, int * rowind, hipStream_t stream);   // CSR -> COO row indices (mkl_coo.cpp:79-90)

@@ -22,18 +22,56 @@ def test_algorithmic_bytes_formula():
     assert b.kkt_edge(1.0) == 240 and b.kkt_edge(1.0 / 8) == 120 and b.kkt_edge(1e-9) == 4
 
 
-def test_traffic_lookup_is_per_spmv_and_matches_the_kernel_that_ran():
+def test_traffic_lookup_is_per_spmv_and_matches_the_kernel_that_ran(tmp_path):
+    """A PMC record is attached only to the kernel build, kernel name and converted format it was collected on."""
     b = _bench()
-    recs = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))["records"]
-    by_tag = {r["tag"]: r for r in recs}
-    head = by_tag["nlpkkt240_sell_c_sigma_f64"]
-    assert b.load_traffic("nlpkkt240", "sell_c_sigma", "f64", "sell_delta_kernel") == head["hbm_bytes_per_launch"]
-    # a different kernel of the same format (plain SELL instead of the delta layout) must not borrow the record
-    assert b.load_traffic("nlpkkt240", "sell_c_sigma", "f64", "sell_kernel") == by_tag["nlpkkt240_sell_c_sigma_f64_sell_delta_2"]["hbm_bytes_per_launch"]
-    coob = by_tag["soc-LiveJournal1_coo_f64_col_blocks_-1"]
-    assert coob["dispatches_per_spmv"] == 2
-    assert b.load_traffic("soc-LiveJournal1", "coo", "f64", "coo_blocked_kernel") == 2 * coob["hbm_bytes_per_launch"]
-    assert b.load_traffic("cant", "csr_scalar", "f64", "csr_scalar_kernel") is None
+    sha = b.kernel_source_sha()
+    assert len(sha) == 16 and sha == b.kernel_source_sha()
+    recs = [
+        dict(workload="nlpkkt240", dtype="f64", kernel="sell_delta_kernel<double, true>", format_name="MI355X_SELLD_64_16384_d",
+             kernel_src_sha=sha, hbm_bytes_per_launch=8_000_000_000),
+        dict(workload="soc-LiveJournal1", dtype="f64", kernel="coo_kernel<double, 4, true>", format_name="MI355X_COO_k4_d",
+             kernel_src_sha=sha, hbm_bytes_per_launch=1_000, dispatches_per_spmv=3),
+        dict(workload="cant", dtype="f64", kernel="csr_vector_kernel<double, 16, false>", format_name="MI355X_CSR_VECTOR_g16_d",
+             kernel_src_sha="0123456789abcdef", hbm_bytes_per_launch=5),
+    ]
+    with open(tmp_path / "traffic_test.json", "w") as f:
+        json.dump(dict(records=recs), f)
+    d = str(tmp_path)
+    assert b.load_traffic("nlpkkt240", "MI355X_SELLD_64_16384_d", "f64", "sell_delta_kernel", pdir=d) == 8_000_000_000
+    # another kernel, another converted format (different options / block counts) or another precision must not borrow it
+    assert b.load_traffic("nlpkkt240", "MI355X_SELLD_64_16384_d", "f64", "sell_kernel", pdir=d) is None
+    assert b.load_traffic("nlpkkt240", "MI355X_SELLD_64_4096_d", "f64", "sell_delta_kernel", pdir=d) is None
+    assert b.load_traffic("nlpkkt240", "MI355X_SELLD_64_16384_d", "f32", "sell_delta_kernel", pdir=d) is None
+    # several dispatches per SpMV: the record holds the per-dispatch figure
+    assert b.load_traffic("soc-LiveJournal1", "MI355X_COO_k4_d", "f64", "coo_kernel", pdir=d) == 3_000
+    # counters collected on other kernel sources are stale
+    assert b.load_traffic("cant", "MI355X_CSR_VECTOR_g16_d", "f64", "csr_vector_kernel", pdir=d) is None
+    # the committed records all carry what the lookup keys on (older rounds' files without it simply never match)
+    for f in os.listdir(os.path.join(ROOT, "profiles")):
+        if f.startswith("traffic_r02") and f.endswith(".json"):
+            for r in json.load(open(os.path.join(ROOT, "profiles", f)))["records"]:
+                assert {"workload", "dtype", "kernel", "format_name", "kernel_src_sha", "hbm_bytes_per_launch"} <= set(r)
+
+
+def test_strided_cpu_sample_covers_the_whole_matrix():
+    import numpy as np
+    b = _bench()
+    rng = np.random.default_rng(0)
+    m = 5000
+    lens = rng.integers(0, 40, m)
+    rp = np.zeros(m + 1, np.int32)
+    np.cumsum(lens, out=rp[1:])
+    ci = rng.integers(0, m, rp[-1]).astype(np.int32)
+    va = rng.uniform(-1, 1, rp[-1])
+    srp, sci, sva, rows, what = b.strided_sample(rp, ci, va, m, max_nnz=20000, chunks=16)
+    assert srp[0] == 0 and len(srp) == len(rows) + 1 and srp[-1] == len(sci) == len(sva) <= 20000 + 16 * 40
+    assert np.all(np.diff(rows) > 0) and rows[0] < m // 16 and rows[-1] > m - m // 8        # spread over the matrix, ascending
+    for k in (0, len(rows) // 2, len(rows) - 1):                                             # rows are copied whole
+        r = rows[k]
+        assert np.array_equal(sci[srp[k]:srp[k + 1]], ci[rp[r]:rp[r + 1]])
+    whole = b.strided_sample(rp, ci, va, m, max_nnz=10 ** 9)
+    assert len(whole[3]) == m and whole[1] is not None
 
 
 def test_default_kernel_per_workload():
@@ -41,3 +79,7 @@ def test_default_kernel_per_workload():
     assert b.DEFAULT_FORMAT["nlpkkt240"] == "sell_c_sigma" and b.DEFAULT_DTYPE.get("nlpkkt240", "f64") == "f64"
     assert b.DEFAULT_FORMAT["soc-LiveJournal1"] == "coo" and b.DEFAULT_OPTS["soc-LiveJournal1"] == {"col_blocks": -1}
     assert b.DEFAULT_DTYPE["pwtk"] == "f32"                      # config 3 of BASELINE.json is the fp32 one
+    # the kernels BASELINE.json names: one wavefront per row on scircuit, SELL-C-sigma on pwtk, merge path on soc-LiveJournal1
+    assert b.NAMED_KERNEL["scircuit"] == ("csr_vector", {"lanes_per_row": 64})
+    assert b.NAMED_KERNEL["pwtk"][0] == "sell_c_sigma" and b.NAMED_KERNEL["soc-LiveJournal1"][0] == "csr_merge"
+    assert set(b.SMALL_CONFIGS) | {"nlpkkt240"} == set(b.WORKLOADS) == set(b.NAMED_KERNEL)

@@ -64,6 +64,9 @@ VARIANTS = [
     ("coo", {"col_blocks": -1}, False),                  # column-blocked COO: segments of rows in LDS, entries by column block
     ("coo", {"col_blocks": 3}, False),
     ("coo", {"col_blocks": 64}, False),
+    ("csr_merge", {"col_blocks": -1}, False),           # the same layout with merge-path-balanced row ranges
+    ("csr_merge", {"col_blocks": 5}, False),
+    ("csr_merge", {"col_blocks": -2}, False),           # forced CSR-order merge path
 ]
 IDS = [f"{f}-{'-'.join(f'{k}{v}' for k, v in o.items()) or 'default'}" for f, o, _ in VARIANTS]
 
@@ -184,7 +187,37 @@ def test_reference_caching_semantics(eng, oracle):
     A.spmv_raw(x, y)                               # same pointers: no download on later calls
     assert np.all(y == 7.0)
     np.testing.assert_allclose(A.download_y(), g["y_csr_d_ones"], rtol=1e-12, atol=1e-13)
+    # a NEW x (another host buffer) must give a new y in the caller's buffer, without always_copy
+    x2 = np.full(info["n"], 2.0)
+    A.spmv_raw(x2, y)
+    np.testing.assert_allclose(y[:info["m"]], 2 * g["y_csr_d_ones"], rtol=1e-12, atol=1e-13)
     A.close()
+
+
+@pytest.mark.parametrize("fmt", ["coo", "csr_merge"])
+def test_blocked_layout_with_several_passes_and_split_rows(eng, oracle, fmt, monkeypatch):
+    """The column-blocked layout's rarely taken paths on small inputs: a workgroup's LDS holds only 64 + 64 rows (so a few
+    hundred rows already need several passes of 8 x 32 workgroups) and every row of 8 or more entries is split over the 32
+    workgroups of its range and recombined by the carry fix-up."""
+    monkeypatch.setenv("SPMV_MI355X_COOB_ROWS", "64")
+    monkeypatch.setenv("SPMV_MI355X_COOB_LONG_MIN", "8")
+    rng = np.random.default_rng(11)
+    cases = [load_case(c)[1] for c in ("huge_row", "empty_rows_formats", "rectangular", "pattern_general")]
+    cases = [(g["row_ptr"], g["col_idx"], g["values"], len(g["row_ptr"]) - 1, len(g["x_rand"])) for g in cases]
+    rp, ci, a = synth(rng, 70000, 70000, "powerlaw")
+    cases.append((rp, ci, a, 70000, 70000))
+    for rp, ci, a, m, n in cases:
+        x = rng.uniform(-1, 1, n)
+        absrow = oracle.csr_spmv(rp, ci, np.abs(a), np.abs(x))
+        for dtype in (np.float64, np.float32):
+            y_ref = oracle.csr_spmv(rp, ci, a, x, dtype)
+            for cb in (-1, 7):
+                A = eng.Matrix(rp, ci, a, m, n, fmt, dtype, col_blocks=cb)
+                assert ("COOB" if fmt == "coo" else "MERGEB") in A.format_name
+                if m >= 70000:
+                    assert "_split" in A.format_name and int(A.format_name.split("_r")[1].split("_")[0]) > 8
+                check(A.spmv(x), y_ref, absrow, dtype, False, f"{A.format_name} m={m}")
+                A.close()
 
 
 def test_beta_accumulate_and_row_blocks(eng, oracle):
