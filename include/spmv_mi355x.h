@@ -89,6 +89,10 @@ typedef struct {
 	                           dealt to workgroups that keep their y in LDS, the entries are ordered by column block (csrc/kernels_coo.hip).
 	                           CSR_MERGE: the same layout with merge-path-balanced row ranges: 0 = auto (taken when the x gathers
 	                           are scattered over a vector no L2 holds), -1 / > 0 = on, -2 = plain CSR-order merge path            */
+	int  sell_window;       /* SELL, 64-row slices: a workgroup owns a group of consecutive slices, copies the group's column window of
+	                           x into LDS and gathers from there; column indices are 16-bit offsets into the window (for banded /
+	                           FEM matrices; csrc/kernels_sell_window.hip). 0 = auto (when every group's window fits), 1 = on, 2 = off */
+	int  sell_group;        /* sell_window: slices per workgroup (1, 2, 4, 8 or 16; times sell_split at most 16 wavefronts); 0 = auto */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */

@@ -57,19 +57,6 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 		for (long r = 0; r <= NR; r++)
 			range_row[r] = (int) std::min<long>(lm, r * per);
 	}
-	// ---- column blocks
-	long W;
-	if (col_blocks > 0)
-		W = std::max<long>(1, (n + col_blocks - 1) / col_blocks);
-	else
-		W = (384L << 10) / A->vbytes;              // ~384 KiB of x per block
-	W = std::max<long>(1, std::min<long>(W, 65536));   // 16-bit column offsets
-	const long B = std::max<long>(1, (n + W - 1) / W);
-	if (B > 16384)
-	{
-		set_error("col_blocks: %ld column blocks of %ld columns (limit 16384)", B, W);
-		return 1;
-	}
 	double v0 = 0;
 	const bool uniform = values_uniform(A, va, lnnz, &v0);
 	// ---- rows to split: longer than 1/8 of a workgroup's fair share of the entries (at most KMAX per range, in row order)
@@ -98,6 +85,69 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 		const long len = rp[row + 1] - rp[row];
 		a = rp[row] + len * j / WGS;
 		b = rp[row] + len * (j + 1) / WGS;
+	};
+	// ---- column blocks, per range (the 32 workgroups of a range walk the same blocks in step): every block spans at most 65 536
+	// columns (16-bit offsets). col_blocks > 0: uniform blocks of ceil(n / col_blocks) columns. col_blocks = -1: EQUI-DEPTH blocks —
+	// as many columns as hold one full batch of entries per workgroup (85 % of it on average: the deal is statistical), so that
+	// every step of the kernel is a full batch wherever the matrix is dense enough, and empty stretches of columns cost nothing.
+	std::vector<std::vector<int>> bstart((size_t) NR);
+	{
+		const long W = col_blocks > 0 ? std::max<long>(1, std::min<long>((n + col_blocks - 1) / col_blocks, 65536)) : 0;
+		const long target = (long) (0.85 * WGS * coo_blocked_batch_entries());
+		#pragma omp parallel num_threads(std::min<int>(spmv::host_threads(), (int) NR))
+		{
+			std::vector<int> hist;
+			#pragma omp for schedule(dynamic, 1)
+			for (long r = 0; r < NR; r++)
+			{
+				const long e0 = rp[range_row[r]], e1 = rp[range_row[r + 1]];
+				std::vector<int> & bs = bstart[(size_t) r];
+				if (e1 == e0)
+					continue;
+				if (W > 0)
+				{
+					int lo = 0x7fffffff, hi = -1;
+					for (long e = e0; e < e1; e++)
+					{
+						lo = std::min(lo, ci[e]);
+						hi = std::max(hi, ci[e]);
+					}
+					for (long b = lo / W; b <= hi / W; b++)
+						bs.push_back((int) (b * W));
+					continue;
+				}
+				hist.assign((size_t) n, 0);
+				for (long e = e0; e < e1; e++)
+					hist[(size_t) ci[e]]++;
+				long start = -1, acc = 0;
+				for (long c = 0; c < n; c++)
+				{
+					const long h = hist[(size_t) c];
+					if (h == 0)
+						continue;
+					if (start < 0 || c - start >= 65536 || (acc > 0 && acc + h > target))
+					{
+						bs.push_back((int) c);
+						start = c;
+						acc = 0;
+					}
+					acc += h;
+				}
+			}
+		}
+	}
+	long B = 1;
+	for (long r = 0; r < NR; r++)
+		B = std::max<long>(B, (long) bstart[(size_t) r].size());
+	if (B > 65536)
+	{
+		set_error("col_blocks: %ld column blocks in one row range (limit 65536)", B);
+		return 1;
+	}
+	// block of column c in range r: the last block starting at or before c
+	auto block_of = [&](long r, int c) {
+		const std::vector<int> & bs = bstart[(size_t) r];
+		return (long) (std::upper_bound(bs.begin(), bs.end(), c) - bs.begin()) - 1;
 	};
 	// ---- entries of every workgroup: offsets first (workgroups in order), then fill + sort
 	std::vector<int> wg_rows((size_t) NT, 0);
@@ -166,7 +216,7 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 			std::fill(pos.begin(), pos.end(), 0);
 			for_each_span([&](long a, long b, unsigned) {
 				for (long e = a; e < b; e++)
-					pos[(size_t) (ci[e] / W) + 1]++;
+					pos[(size_t) block_of(r, ci[e]) + 1]++;
 			});
 			sb[0] = (int) wg_nnz[t];
 			for (long b = 0; b < B; b++)
@@ -176,9 +226,9 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 			for_each_span([&](long a, long b, unsigned l) {
 				for (long e = a; e < b; e++)
 				{
-					const long blk = ci[e] / W;
+					const long blk = block_of(r, ci[e]);
 					const int at = pos[(size_t) blk]++;
-					ent[(size_t) at] = ((unsigned) (ci[e] - blk * W) << 16) | l;
+					ent[(size_t) at] = ((unsigned) (ci[e] - bstart[(size_t) r][(size_t) blk]) << 16) | l;
 					if (!uniform)
 						pval[(size_t) at] = va[e];
 				}
@@ -211,34 +261,40 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 		set_error("column-blocked layout: %ld entries placed, %ld expected", wg_nnz[NT], lnnz);
 		return 1;
 	}
-	// ---- column blocks a range's workgroups walk together: first to last block any of them has entries in
-	std::vector<int> range_blk((size_t) 2 * NR, 0);
+	// ---- per range: number of blocks, then the first column of every block
+	std::vector<int> range_blk((size_t) NR * (B + 1), 0);
 	int max_rows = 0;
 	for (long r = 0; r < NR; r++)
 	{
-		long lo = B, hi = 0;
+		const std::vector<int> & bs = bstart[(size_t) r];
+		range_blk[(size_t) r * (B + 1)] = (int) bs.size();
+		for (size_t b = 0; b < bs.size(); b++)
+			range_blk[(size_t) r * (B + 1) + 1 + b] = bs[b];
 		for (long t = r * WGS; t < (r + 1) * WGS; t++)
-		{
-			const int * sb = seg_blk.data() + (size_t) t * (B + 1);
-			for (long b = 0; b < B; b++)
-				if (sb[b + 1] > sb[b])
-				{
-					lo = std::min(lo, b);
-					hi = std::max(hi, b + 1);
-				}
 			max_rows = std::max(max_rows, wg_rows[(size_t) t]);
-		}
-		range_blk[(size_t) 2 * r] = (int) (hi > lo ? lo : 0);
-		range_blk[(size_t) 2 * r + 1] = (int) (hi > lo ? hi : 0);
 	}
 	if (upload_ints(wg_rows.data(), wg_rows.size(), &A->d_coob_wg_rows) || upload_ints(range_row.data(), range_row.size(), &A->d_coob_range_row) ||
 	    upload_ints(seg_blk.data(), seg_blk.size(), &A->d_coob_seg_blk) || upload_ints(range_blk.data(), range_blk.size(), &A->d_coob_range_blk) ||
 	    upload_ints(range_long.data(), range_long.size(), &A->d_coob_range_long) || upload_ints(long_row.data(), long_row.size(), &A->d_coob_long_row) ||
 	    dev_alloc_bytes(&A->d_coob_carry, (size_t) std::max<long>(NL, 1) * WGS * A->vbytes) ||
-	    upload_bytes(ent.data(), (size_t) lnnz * 4, STREAM_SLACK * 4, (void **) &A->d_coob_ent))
+	    upload_bytes(ent.data(), (size_t) lnnz * 4, (size_t) coo_blocked_entry_slack() * 4, (void **) &A->d_coob_ent))
 		return 1;
-	if (!uniform && upload_values(A, pval.data(), (size_t) lnnz, &A->d_val))
-		return 1;
+	if (!uniform)
+	{
+		// narrowed values with the same slack as the entries (the kernel's loads are unconditional)
+		const size_t slack = (size_t) coo_blocked_entry_slack() * A->vbytes;
+		if (A->f32)
+		{
+			std::vector<float> pf32((size_t) std::max<long>(lnnz, 1));
+			#pragma omp parallel for num_threads(spmv::host_threads())
+			for (long e = 0; e < lnnz; e++)
+				pf32[(size_t) e] = (float) pval[(size_t) e];
+			if (upload_bytes(pf32.data(), (size_t) lnnz * 4, slack, &A->d_val))
+				return 1;
+		}
+		else if (upload_bytes(pval.data(), (size_t) lnnz * 8, slack, &A->d_val))
+			return 1;
+	}
 	if (uniform)
 	{
 		A->cfg.unit = 1;
@@ -246,12 +302,12 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 	}
 	A->coob_ranges = (int) NR;
 	A->coob_blocks = (int) B;
-	A->coob_block_cols = (int) W;
+	A->coob_block_cols = 0;
 	A->coob_num_long = (int) NL;
-	A->coob_lds = (int) (((long) std::max(max_rows, 1) * A->vbytes + 15) / 16 * 16);
+	A->coob_lds = (int) (((long) std::max(max_rows, 1) * 8 + 15) / 16 * 16);      // fp64 slots for both precisions
 	A->cfg.map = xcd_map_uniform(1, 0);
-	A->mem_footprint = (double) lnnz * (4 + (uniform ? 0 : A->vbytes)) + (double) NT * (B + 2) * 4 + (4.0 * NR + 2) * 4 + NL * (4.0 + WGS * A->vbytes);
-	snprintf(A->format_name, sizeof(A->format_name), "MI355X_%s_r%ld_b%ld%s%s_%s", merge_balance ? "MERGEB" : "COOB", NR, B, NL ? "_split" : "",
+	A->mem_footprint = (double) lnnz * (4 + (uniform ? 0 : A->vbytes)) + (double) NT * (B + 2) * 4 + (double) NR * (B + 4) * 4 + NL * (4.0 + WGS * A->vbytes);
+	snprintf(A->format_name, sizeof(A->format_name), "MI355X_%s_r%ld_%s%ld%s%s_%s", merge_balance ? "MERGEB" : "COOB", NR, col_blocks > 0 ? "b" : "e", B, NL ? "_split" : "",
 			uniform ? "_unit" : "", pf);
 	snprintf(A->kernel_name, sizeof(A->kernel_name), "coo_blocked_kernel");
 	A->kernel_block = 1024;

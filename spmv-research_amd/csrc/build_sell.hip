@@ -313,6 +313,124 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 	return 0;
 }
 
+// SELL-64 with the slice group's x window in LDS (kernels_sell_window.hip). Groups of NS consecutive slices = contiguous row
+// ranges of 64*NS rows, sorted by length inside the group (descending, stable: radix_sort.c:103-122 semantics with
+// sigma = 64*NS). Returns 0 = built, 1 = error, 2 = not applicable (a group's window is wider than 65 536 columns or than
+// the LDS budget): the caller falls back to the delta layout.
+static int
+build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va, int NS, int S, long lds_budget_bytes)
+{
+	const long m = A->m;
+	constexpr int C = 64;
+	const long num_slices = (m + C - 1) / C;
+	const long num_groups = (num_slices + NS - 1) / NS;
+	const long sigma = (long) NS * C;
+	if (m == 0 || A->nnz == 0)
+		return 2;
+	// ---- windows
+	std::vector<int> grp((size_t) num_groups * 4, 0);
+	long too_wide = 0;
+	int max_w = 0;
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 16) reduction(+ : too_wide) reduction(max : max_w)
+	for (long g = 0; g < num_groups; g++)
+	{
+		const long r0 = g * sigma, r1 = std::min(m, r0 + sigma);
+		int lo = 0x7fffffff, hi = -1;
+		for (long j = rp[r0]; j < rp[r1]; j++)
+		{
+			lo = std::min(lo, ci[j]);
+			hi = std::max(hi, ci[j]);
+		}
+		if (hi < 0)
+			lo = 0;
+		const long w = hi < 0 ? 1 : (long) hi - lo + 1;
+		if (w > 65536 || w * (long) A->vbytes > lds_budget_bytes)
+			too_wide++;
+		grp[(size_t) 4 * g] = lo;
+		grp[(size_t) 4 * g + 1] = (int) std::min<long>(w, 0x7fffffffL);
+		grp[(size_t) 4 * g + 2] = (int) (g * NS);
+		grp[(size_t) 4 * g + 3] = (int) std::min<long>(NS, num_slices - g * NS);
+		max_w = std::max(max_w, grp[(size_t) 4 * g + 1]);
+	}
+	if (too_wide)
+		return 2;
+	// ---- sort inside the groups, slice widths
+	std::vector<int> row_of_sorted((size_t) m);
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 16)
+	for (long g = 0; g < num_groups; g++)
+	{
+		const long s0 = g * sigma, e0 = std::min(m, s0 + sigma);
+		int maxlen = 0;
+		for (long i = s0; i < e0; i++)
+			maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
+		std::vector<long> cnt((size_t) maxlen + 2, 0);
+		for (long i = s0; i < e0; i++)
+			cnt[maxlen - (rp[i + 1] - rp[i]) + 1]++;
+		for (int b = 0; b <= maxlen; b++)
+			cnt[b + 1] += cnt[b];
+		for (long i = s0; i < e0; i++)
+			row_of_sorted[s0 + cnt[maxlen - (rp[i + 1] - rp[i])]++] = (int) i;
+	}
+	std::vector<int64_t> sdesc(2 * ((size_t) num_slices + 1), 0);
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		const int o = row_of_sorted[sl * C];                       // the slice's longest row is its first
+		const long width = rp[o + 1] - rp[o];
+		sdesc[2 * (sl + 1)] = sdesc[2 * sl] + (width + 3) / 4 * 4 * C;           // values and indices: whole groups of 4 steps
+		sdesc[2 * (sl + 1) + 1] = sdesc[2 * sl + 1] + (width + 3) / 4 * 4 * C;
+	}
+	const int64_t nnz_ext = sdesc[2 * num_slices], idx_count = sdesc[2 * num_slices + 1];
+	std::vector<double> val((size_t) std::max<int64_t>(nnz_ext, 1));
+	std::vector<unsigned short> idx((size_t) std::max<int64_t>(idx_count, 1), 0);
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 64)
+	for (long sl = 0; sl < num_slices; sl++)
+	{
+		const int lo = grp[(size_t) 4 * (sl / NS)];
+		const int64_t vb = sdesc[2 * sl], ib = sdesc[2 * sl + 1];
+		const long width = (sdesc[2 * sl + 2] - vb) / C;              // a multiple of 4
+		for (int r = 0; r < C; r++)
+		{
+			const long i = sl * C + r;
+			long js = 0, len = 0;
+			if (i < m)
+			{
+				const int o = row_of_sorted[i];
+				js = rp[o];
+				len = rp[o + 1] - rp[o];
+			}
+			// padding: value 0 times a window entry the row already reads (its last column), or the window's first
+			const unsigned short pad = len > 0 ? (unsigned short) (ci[js + len - 1] - lo) : (unsigned short) 0;
+			for (long k = 0; k < width; k++)
+			{
+				val[(size_t) (vb + k * C + r)] = k < len ? va[js + k] : 0.0;
+				idx[(size_t) (ib + (k / 4) * 4 * C + r * 4 + k % 4)] = k < len ? (unsigned short) (ci[js + k] - lo) : pad;
+			}
+		}
+	}
+	A->sell_slices = num_slices;
+	A->sell_nnz_ext = nnz_ext;
+	A->sell_idx_bytes = idx_count * 2;
+	A->sellw_groups = (int) num_groups;
+	A->sellw_ns = NS;
+	A->sell_split = S;
+	A->sellw_lds = (int) (((long) max_w * A->vbytes + 15) / 16 * 16);
+	{
+		// XCD map over the groups, balanced by their stored entries
+		std::vector<int64_t> gp((size_t) num_groups + 1, 0);
+		for (long g = 0; g < num_groups; g++)
+			gp[(size_t) g + 1] = sdesc[2 * std::min<long>(num_slices, (g + 1) * NS)];
+		A->cfg.map = xcd_map_balanced(gp.data(), num_groups, 1, resolve_remap(A->remap, num_groups));
+	}
+	if (upload_ints(grp.data(), grp.size(), &A->d_sellw_grp) || dev_alloc(&A->d_sell_desc, sdesc.size()))
+		return 1;
+	HIP_TRY(hipMemcpy(A->d_sell_desc, sdesc.data(), sdesc.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+	if (upload_bytes(idx.data(), (size_t) idx_count * 2, 1024, (void **) &A->d_sell_idx) || upload_values(A, val.data(), (size_t) nnz_ext, &A->d_val) ||
+	    upload_ints(row_of_sorted.data(), (size_t) m, &A->d_row_of_sorted))
+		return 1;
+	A->mem_footprint = (double) (num_slices + 1) * 16 + (double) num_groups * 16 + (double) nnz_ext * A->vbytes + (double) idx_count * 2 + (double) m * 4;
+	return 0;
+}
+
 int
 build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * rp, const int * ci, const double * va)
 {
@@ -325,14 +443,12 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 	if (C != 16 && C != 32 && C != 64)
 	{
 		set_error("sell_c must be 16, 32 or 64 (got %d)", C);
-		rc = 1;
 		return 1;
 	}
 	long sigma = o.sell_sigma ? o.sell_sigma : 16384;
 	if (sigma < C || sigma % C)
 	{
 		set_error("sell_sigma (%ld) must be a positive multiple of sell_c (%d)", sigma, C);
-		rc = 1;
 		return 1;
 	}
 	A->sell_c = C;
@@ -346,7 +462,6 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 		if (S != 1 && S != 2 && S != 4)
 		{
 			set_error("sell_split must be 1, 2 or 4 (got %d)", S);
-			rc = 1;
 			return 1;
 		}
 		A->sell_split = A->sell_delta ? S : 1;
@@ -354,8 +469,52 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 	if (o.sell_delta == 1 && C != 64)
 	{
 		set_error("sell_delta needs sell_c = 64 (one lane per row)");
-		rc = 1;
 		return 1;
+	}
+	// ---- x window in LDS + 16-bit indices (banded / FEM matrices): sell_window 0 = auto, 1 = on (error when not applicable), 2 = off
+	if (C == 64 && o.sell_window != 2 && o.sell_delta != 2 && (o.sell_window == 1 || o.convert_on != 2))
+	{
+		const long slices = (lm + 63) / 64;
+		const double mean = lm > 0 ? (double) A->nnz / lm : 0;
+		// slices per workgroup: from sell_sigma when given, else enough groups for two per CU; waves per slice: enough wavefronts
+		// to occupy the chip when the matrix has few slices
+		int NS = o.sell_group ? o.sell_group : o.sell_sigma ? (int) std::min<long>(16, std::max<long>(1, sigma / 64)) : 0;
+		int S = o.sell_split ? o.sell_split : (slices >= 3072 ? 1 : slices >= 1536 ? 2 : 4);
+		if (NS == 0)
+			NS = 16 / S;          // 16 wavefronts per workgroup: measured best on the cant (4 x 4) and pwtk (16 x 1) twins — the window is
+			                      // copied once per workgroup, so fewer, larger groups copy less
+		if (NS < 1 || NS * S > 16 || (NS & (NS - 1)))
+		{
+			if (o.sell_window == 1)
+			{
+				set_error("sell_window: %d slices x %d waves per workgroup (a power of two, at most 16 waves)", NS, S);
+				return 1;
+			}
+		}
+		else if (o.sell_window == 1 || (mean >= 8 && A->nnz >= (1L << 20) && A->nnz < (1L << 28)))
+		{
+			const int took = build_sell_window(A, rp, ci, va, NS, S, sell_window_lds_budget());
+			if (took == 1)
+				return 1;
+			if (took == 0)
+			{
+				A->sell_window = true;
+				A->sell_delta = false;
+				A->sell_sigma = 64L * NS;
+				if (S > 1)
+					snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELLW_64_%d_w%d_%s", 64 * NS, S, pf);
+				else
+					snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELLW_64_%d_%s", 64 * NS, pf);
+				snprintf(A->kernel_name, sizeof(A->kernel_name), "sell_window_kernel");
+				A->kernel_block = 64 * NS * S;
+				return 0;
+			}
+			if (o.sell_window == 1)
+			{
+				set_error("sell_window: a slice group's column window exceeds 65 536 columns or the LDS budget");
+				return 1;
+			}
+		}
 	}
 	rc = A->sell_delta ? build_sell_delta(A, rp, ci, va) : build_sell(A, rp, ci, va);
 	if (A->sell_delta && A->sell_split > 1)

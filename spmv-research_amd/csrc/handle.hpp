@@ -61,6 +61,9 @@ struct spmv_mi355x_matrix {
 	int64_t * d_sell_desc = nullptr;
 	unsigned char * d_sell_idx = nullptr;
 	long sell_idx_bytes = 0;
+	bool sell_window = false;              // x window of a slice group in LDS, 16-bit window-relative indices (kernels_sell_window.hip)
+	int * d_sellw_grp = nullptr;           // [groups][4]: window start, width, first slice, slices
+	int sellw_groups = 0, sellw_ns = 0, sellw_lds = 0;
 	long sell_mode_slices[4] = {0, 0, 0, 0};  // slices stored with 8-bit / 16-bit / 32-bit indices / none (affine)
 	// COO
 	int coo_k = 0, coo_num_waves = 0;

@@ -218,34 +218,69 @@ struct CoobBatch {
 	T v[UNIT ? 1 : COOB_U];
 };
 
+// Branch-free: the entry arrays carry COOB_SLACK spare entries, so a lane past the end of its block loads something valid and
+// discards it. Straight-line loads let the compiler count the outstanding memory operations exactly (s_waitcnt vmcnt(N));
+// with a branch around every load it fell back to vmcnt(0) before each gather and the prefetch below was waited for at once.
 template <typename T, bool UNIT>
 __device__ __forceinline__ void
-coob_load(CoobBatch<T, UNIT> & b, const unsigned * __restrict__ ent, const T * __restrict__ val, int first, int end)
+coob_load(CoobBatch<T, UNIT> & b, const unsigned * __restrict__ ent, const T * __restrict__ val, int first)
 {
 	#pragma unroll
 	for (int u = 0; u < COOB_U; u++)
 	{
-		const int ee = first + u * COOB_THREADS;
-		const bool ok = ee < end;
 		// the entry streams are read once: nontemporal, so that they do not push the x block out of L2
-		b.e[u] = ok ? ld_stream<true>(ent + ee) : 0u;
+		b.e[u] = ld_stream<true>(ent + first + u * COOB_THREADS);
 		if constexpr (!UNIT)
-			b.v[u] = ok ? ld_stream<true>(val + ee) : (T) 0;
+			b.v[u] = ld_stream<true>(val + first + u * COOB_THREADS);
 	}
 }
 
+// Lanes past the end of the block issue NO gather: the vector memory pipeline handles a gather lane by lane (PMC: one L1
+// access per lane), and dummy gathers for the idle lanes cost 316 instead of 244 us on the soc-LiveJournal1 twin.
 template <typename T, bool UNIT>
 __device__ __forceinline__ void
-coob_consume(const CoobBatch<T, UNIT> & b, const T * __restrict__ xb, T * __restrict__ ys, T unit, int first, int end)
+coob_gather(T (&xv)[COOB_U], const CoobBatch<T, UNIT> & b, const T * __restrict__ xb, int first, int end)
 {
-	T xv[COOB_U];
 	#pragma unroll
 	for (int u = 0; u < COOB_U; u++)
-		xv[u] = (first + u * COOB_THREADS < end) ? xb[b.e[u] >> 16] : (T) 0;
+	{
+		xv[u] = 0;
+		if (first + u * COOB_THREADS < end)
+			xv[u] = xb[b.e[u] >> 16];
+	}
+}
+
+// The LDS copy of y is fp64 for both precisions: ds_add_f32 runs at half the rate of ds_add_f64 on this part (fp32 on the
+// soc-LiveJournal1 twin: 487 us with float atomics, 259 us with plain stores in their place), and the sums are more accurate.
+template <typename T, bool UNIT>
+__device__ __forceinline__ void
+coob_add(const T (&xv)[COOB_U], const CoobBatch<T, UNIT> & b, double * __restrict__ ys, T unit, int first, int end)
+{
 	#pragma unroll
 	for (int u = 0; u < COOB_U; u++)
 		if (first + u * COOB_THREADS < end)
-			unsafeAtomicAdd(&ys[b.e[u] & 0xffffu], (UNIT ? unit : b.v[u]) * xv[u]);
+			unsafeAtomicAdd(&ys[b.e[u] & 0xffffu], (double) (UNIT ? unit : b.v[u]) * (double) xv[u]);
+}
+
+// One column block of one workgroup: gathers of the current batch first, THEN the prefetch of the batch two blocks ahead
+// (vector memory operations complete in issue order: everything issued before the gathers would have to land before they do),
+// then the LDS adds, then whatever the block holds beyond one batch.
+template <typename T, bool UNIT>
+__device__ __forceinline__ void
+coob_step(const CoobBatch<T, UNIT> & cur, CoobBatch<T, UNIT> & pf, const unsigned * __restrict__ ent, const T * __restrict__ val,
+		const T * __restrict__ xb, double * __restrict__ ys, T unit, int e0, int e1, int pf_first, int tid)
+{
+	T xv[COOB_U];
+	coob_gather<T, UNIT>(xv, cur, xb, e0 + tid, e1);
+	coob_load<T, UNIT>(pf, ent, val, pf_first + tid);
+	coob_add<T, UNIT>(xv, cur, ys, unit, e0 + tid, e1);
+	for (int e = e0 + tid + COOB_U * COOB_THREADS; e < e1; e += COOB_U * COOB_THREADS)
+	{
+		CoobBatch<T, UNIT> more;
+		coob_load<T, UNIT>(more, ent, val, e);
+		coob_gather<T, UNIT>(xv, more, xb, e, e1);
+		coob_add<T, UNIT>(xv, more, ys, unit, e, e1);
+	}
 }
 
 template <typename T, bool UNIT>
@@ -253,10 +288,10 @@ __global__ __launch_bounds__(COOB_THREADS) void
 coo_blocked_kernel(const int * __restrict__ wg_rows, const int * __restrict__ range_row, const int * __restrict__ seg_blk,
 		const int * __restrict__ range_blk, const int * __restrict__ range_long, const unsigned * __restrict__ ent,
 		const T * __restrict__ val, const T * __restrict__ x, T * __restrict__ y, T * __restrict__ carry,
-		int ranges_per_xcd, int num_blocks, int block_cols, T unit, int beta)
+		int ranges_per_xcd, int max_blocks, int sync_every, T unit, int beta)
 {
 	extern __shared__ __align__(16) unsigned char coob_smem[];
-	T * ys = reinterpret_cast<T *>(coob_smem);
+	double * ys = reinterpret_cast<double *>(coob_smem);
 	// workgroups are dealt round-robin to the XCDs: the i-th workgroup of XCD k is the (i % 32)-th of its (i / 32)-th range
 	const int xcd = (int) blockIdx.x % NUM_XCD;
 	const int i = (int) blockIdx.x / NUM_XCD;
@@ -269,29 +304,37 @@ coo_blocked_kernel(const int * __restrict__ wg_rows, const int * __restrict__ ra
 	const int tid = (int) threadIdx.x;
 	for (int l = tid; l < nloc; l += COOB_THREADS)
 		ys[l] = 0;
-	const int * sb = seg_blk + (size_t) t * (num_blocks + 1);
-	const int b0 = range_blk[2 * range], b1 = range_blk[2 * range + 1];
-	CoobBatch<T, UNIT> cur, nxt;
-	int e0 = b0 < b1 ? sb[b0] : 0, e1 = b0 < b1 ? sb[b0 + 1] : 0;
-	coob_load<T, UNIT>(cur, ent, val, e0 + tid, e1);
-	__syncthreads();
-	for (int b = b0; b < b1; b++)
+	const int * sb = seg_blk + (size_t) t * (max_blocks + 1);
+	const int * bc = range_blk + (size_t) range * (max_blocks + 1);        // [0] = blocks of this range, [1 + b] = first column of block b
+	const int b0 = 0, b1 = bc[0];
+	auto xblk = [&](int b) { return x + bc[1 + (b < b1 ? b : b1 - 1)]; };
+	// entry offset of block b, clamped to the last boundary (blocks past the range's last hold nothing)
+	auto at = [&](int b) { return sb[b < b1 ? b : b1]; };
+	CoobBatch<T, UNIT> q0, q1, q2;
+	if (b0 < b1)
 	{
-		const int n1 = b + 1 < b1 ? sb[b + 2] : e1;      // next block: [e1, n1)
-		coob_load<T, UNIT>(nxt, ent, val, e1 + tid, n1);
-		const T * xb = x + (size_t) b * block_cols;
-		coob_consume<T, UNIT>(cur, xb, ys, unit, e0 + tid, e1);
-		for (int e = e0 + tid + COOB_U * COOB_THREADS; e < e1; e += COOB_U * COOB_THREADS)
-		{
-			CoobBatch<T, UNIT> more;
-			coob_load<T, UNIT>(more, ent, val, e, e1);
-			coob_consume<T, UNIT>(more, xb, ys, unit, e, e1);
-		}
-		__syncthreads();                     // keep the waves of the workgroup on the same column block
-		cur = nxt;
-		e0 = e1;
-		e1 = n1;
+		coob_load<T, UNIT>(q0, ent, val, at(b0) + tid);
+		coob_load<T, UNIT>(q1, ent, val, at(b0 + 1) + tid);
 	}
+	__syncthreads();
+	int since = 0;
+	// three batches rotate through q0, q1, q2 (compile-time names: registers, not an indexed array)
+	for (int b = b0; b < b1; b += 3)
+	{
+		coob_step<T, UNIT>(q0, q2, ent, val, xblk(b), ys, unit, at(b), at(b + 1), at(b + 2), tid);
+		if (++since == sync_every) { since = 0; __syncthreads(); }    // keep the waves of the workgroup on the same column blocks
+		if (b + 1 < b1)
+		{
+			coob_step<T, UNIT>(q1, q0, ent, val, xblk(b + 1), ys, unit, at(b + 1), at(b + 2), at(b + 3), tid);
+			if (++since == sync_every) { since = 0; __syncthreads(); }
+		}
+		if (b + 2 < b1)
+		{
+			coob_step<T, UNIT>(q2, q1, ent, val, xblk(b + 2), ys, unit, at(b + 2), at(b + 3), at(b + 4), tid);
+			if (++since == sync_every) { since = 0; __syncthreads(); }
+		}
+	}
+	__syncthreads();
 	// local row l = chunk (l / 16) of this workgroup, row l % 16 of the chunk; its chunks are j, j + 32, j + 64, ... of the range
 	const int r0 = range_row[range], r1 = range_row[range + 1];
 	const int k0 = range_long[range], nlong = range_long[range + 1] - k0;     // split rows of this range: the last `nlong` LDS slots
@@ -300,10 +343,10 @@ coo_blocked_kernel(const int * __restrict__ wg_rows, const int * __restrict__ ra
 	{
 		const int row = r0 + ((l / COOB_CHUNK) * COOB_WGS + j) * COOB_CHUNK + l % COOB_CHUNK;
 		if (row < r1)
-			y[row] = beta ? y[row] + ys[l] : ys[l];
+			y[row] = (T) (beta ? (double) y[row] + ys[l] : ys[l]);
 	}
 	if (tid < nlong)
-		carry[(size_t) (k0 + tid) * COOB_WGS + j] = ys[nnorm + tid];
+		carry[(size_t) (k0 + tid) * COOB_WGS + j] = (T) ys[nnorm + tid];
 }
 
 // adds the 32 partial sums of every split row to y, in workgroup order (deterministic given the partial sums)
@@ -323,13 +366,16 @@ coo_blocked_fixup_kernel(const int * __restrict__ long_row, const T * __restrict
 int coo_blocked_wgs_per_range() { return COOB_WGS; }
 int coo_blocked_chunk_rows() { return COOB_CHUNK; }
 int coo_blocked_max_long_rows() { return 64; }     // split rows per range (LDS slots set aside in every workgroup)
+int coo_blocked_batch_entries() { return COOB_U * COOB_THREADS; }         // entries one workgroup takes per batch
+int coo_blocked_entry_slack() { return COOB_U * COOB_THREADS + 64; }      // spare entries behind the entry arrays (branch-free loads)
 
 int
 coo_blocked_rows_cap(bool f32)
 {
 	// rows of y one workgroup keeps in LDS: the CU's 160 KiB less a little for the runtime, at most what 16 bits index
+	(void) f32;                                                    // the LDS copy of y is fp64 for both precisions
 	const int bytes = 160 * 1024 - 512;
-	int rows = bytes / (f32 ? 4 : 8) / COOB_CHUNK * COOB_CHUNK;
+	int rows = bytes / 8 / COOB_CHUNK * COOB_CHUNK;
 	if (const char * e = getenv("SPMV_MI355X_COOB_ROWS"))          // tests: a small cap makes small matrices take several passes
 		if (atoi(e) >= COOB_CHUNK && atoi(e) <= rows)
 			rows = atoi(e) / COOB_CHUNK * COOB_CHUNK + coo_blocked_max_long_rows();
@@ -342,6 +388,9 @@ coo_blocked_launch(const int * wg_rows, const int * range_row, const int * seg_b
 		const int * long_row, int num_long, const unsigned * ent, const void * val, const void * x, void * y, void * carry, int num_ranges,
 		int num_blocks, int block_cols, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
+	// The layout assumes ONE workgroup per CU (32 per XCD, in step): with less than half of the CU's 160 KiB each, two could share
+	// a CU and leave another idle — ask for more than half.
+	lds_bytes = std::max(lds_bytes, 84 * 1024);
 	// more than 64 KiB of dynamic LDS has to be granted per kernel function, once per device
 	static int granted[64] = {0};
 	int dev = 0;
@@ -358,12 +407,14 @@ coo_blocked_launch(const int * wg_rows, const int * range_row, const int * seg_b
 	if (grid == 0)
 		return 0;
 	const int per_xcd = num_ranges / NUM_XCD;
+	// column blocks between workgroup barriers (measured on the soc-LiveJournal1 twin: 1, 2 and 4 within 2 %, never: +5 %)
+	static const int sync_every = [] { const char * e = getenv("SPMV_MI355X_COOB_SYNC"); return e ? atoi(e) : 1; }();
 	if (cfg.unit)
 		hipLaunchKernelGGL((coo_blocked_kernel<T, true>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, wg_rows, range_row, seg_blk, range_blk,
-				range_long, ent, (const T *) nullptr, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, block_cols, (T) cfg.unit_value, cfg.beta);
+				range_long, ent, (const T *) nullptr, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, sync_every, (T) cfg.unit_value, cfg.beta);
 	else
 		hipLaunchKernelGGL((coo_blocked_kernel<T, false>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, wg_rows, range_row, seg_blk, range_blk,
-				range_long, ent, (const T *) val, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, block_cols, (T) 0, cfg.beta);
+				range_long, ent, (const T *) val, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, sync_every, (T) 0, cfg.beta);
 	HIP_TRY(hipGetLastError());
 	if (num_long > 0)
 	{

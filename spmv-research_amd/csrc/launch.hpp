@@ -66,6 +66,12 @@ int launch_sell(bool f32, int C, const int64_t * slice_ptr, const int * col, con
 int launch_sell_delta(bool f32, int waves_per_slice, const int64_t * desc, const unsigned char * idx, const void * val, const int * row_of_sorted,
 		const void * x, void * y, int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
+// SELL-64 with the slice group's x window in LDS and 16-bit window-relative indices (kernels_sell_window.hip)
+int sell_window_lds_budget();
+int launch_sell_window(bool f32, int waves_per_slice, int slices_per_group, const int * grp, const int64_t * sdesc, const unsigned short * idx,
+		const void * val, const int * row_of_sorted, const void * x, void * y, int m, int lds_window_bytes, const LaunchCfg & cfg,
+		hipStream_t stream, long * grid_out);
+
 // CSR -> SELL-64-sigma-delta on the GPU (convert_sell.hip); outputs are device arrays owned by the caller
 int sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
 		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
@@ -81,6 +87,8 @@ int launch_coo(bool f32, int items_per_lane, const int * rowind, const int * col
 int coo_blocked_rows_cap(bool f32);                                    // rows of y one workgroup can keep in LDS
 int coo_blocked_wgs_per_range();                                       // workgroups a row range is dealt to (32 = CUs per XCD)
 int coo_blocked_chunk_rows();                                          // rows per chunk of that round-robin deal (16)
+int coo_blocked_batch_entries();                                       // entries a workgroup consumes per batch (8 per lane)
+int coo_blocked_entry_slack();                                         // spare entries the entry / value arrays need behind their end
 int coo_blocked_max_long_rows();                                       // rows per range that may be split over its workgroups
 int launch_coo_blocked(bool f32, const int * wg_rows, const int * range_row, const int * seg_blk, const int * range_blk, const int * range_long,
 		const int * long_row, int num_long, const unsigned * ent, const void * val, const void * x, void * y, void * carry, int num_ranges,

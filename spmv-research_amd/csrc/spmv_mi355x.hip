@@ -222,7 +222,10 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 					A->merge_num_tiles, A->d_coords, A->d_carry_row, A->d_carry_val, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_SELL_C_SIGMA:
-			rc = A->sell_delta
+			rc = A->sell_window
+			     ? launch_sell_window(A->f32, A->sell_split, A->sellw_ns, A->d_sellw_grp, A->d_sell_desc, (const unsigned short *) A->d_sell_idx, A->d_val,
+					A->d_row_of_sorted, x, y, (int) A->m, A->sellw_lds, cfg, st, &grid)
+			     : A->sell_delta
 			     ? launch_sell_delta(A->f32, A->sell_split, A->d_sell_desc, A->d_sell_idx, A->d_val, A->d_row_of_sorted, x, y, (int) A->m,
 					(int) A->sell_slices, cfg, st, &grid)
 			     : launch_sell(A->f32, A->sell_c, A->d_slice_ptr, A->d_col, A->d_val, A->d_row_of_sorted, x, y, (int) A->m,
@@ -367,6 +370,11 @@ spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma
 	if (A->format != SPMV_MI355X_SELL_C_SIGMA)
 	{
 		set_error("not a SELL handle");
+		return 1;
+	}
+	if (A->sell_window)
+	{
+		set_error("sell_layout: not available for the LDS-window layout (16-bit window-relative indices)");
 		return 1;
 	}
 	HIP_TRY(hipSetDevice(A->device));

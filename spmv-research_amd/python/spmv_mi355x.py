@@ -26,7 +26,8 @@ class Opts(C.Structure):
                 ("stream_mode", C.c_int),
                 ("row_begin", C.c_long), ("row_end", C.c_long), ("col_begin", C.c_long), ("col_end", C.c_long),
                 ("col_filter_mode", C.c_int), ("sell_delta", C.c_int), ("convert_on", C.c_int),
-                ("symmetric_input", C.c_int), ("rows_per_group", C.c_int), ("col_blocks", C.c_int)]
+                ("symmetric_input", C.c_int), ("rows_per_group", C.c_int), ("col_blocks", C.c_int),
+                ("sell_window", C.c_int), ("sell_group", C.c_int)]
 
 
 # every symbol declared in include/spmv_mi355x.h (checked by tests/test_abi.py)
