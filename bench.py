@@ -90,12 +90,8 @@ def parse(argv=None):
                     help="N>1: 'rows' = the reference's nnz-balanced contiguous row blocks of A as it is; 'graph' = the same balance "
                          "cut out of a breadth-first order of the matrix graph; 'auto' = whichever makes the busiest rank read "
                          "fewer remote x entries")
-    ap.add_argument("--layout", default="auto", choices=["auto", "original", "padded"],
-                    help="N>1 with the graph partition: 'original' = every rank keeps a full-length x in the matrix's ORIGINAL "
-                         "numbering and the halo moves by pack -> send/recv -> scatter; 'padded' = P A P^T with x as padded "
-                         "slices exchanged in place")
     ap.add_argument("--halo", default="auto", choices=["auto", "alltoall", "p2p"],
-                    help="original layout: how the packed halo segments move (auto = all_to_all_single if it validates, else p2p)")
+                    help="N>1, graph partition: how the packed halo segments move (auto = all_to_all_single if it validates, else p2p)")
     ap.add_argument("--variants", default="auto", choices=["auto", "both", "one"],
                     help="N>1: 'both' = time the north-star scheme (row blocks + allgather(x)) AND the auto choice in one run and "
                          "report both under \"variants\" (value = the faster); auto = both unless --partition/--exchange is given")

@@ -83,6 +83,17 @@ int  spmv_host_gen_kkt(long N, unsigned long seed, spmv_host_csr * out);
  * (row_ptr may be NULL to query m), and rows [row_begin,row_end) as a local CSR with global column indices. */
 int  spmv_host_gen_kkt_row_ptr(long N, int32_t * row_ptr /* [m+1] or NULL */, long * m_out, long * nnz_out);
 int  spmv_host_gen_kkt_block(long N, unsigned long seed, long row_begin, long row_end, spmv_host_csr * out);
+/* An arbitrary ascending list of rows of the same matrix as a local CSR (a rank's rows under a graph partition). */
+int  spmv_host_gen_kkt_rows(long N, unsigned long seed, const int32_t * rows, long count, spmv_host_csr * out);
+/* In place: in a fraction `frac` of the rows every off-diagonal column moves by a random offset in [-span, span] (rows stay
+ * sorted and duplicate-free). Breaks the translation invariance of a generated matrix: bench.py --jitter measures how much
+ * of the compressed-index SELL format's advantage rests on it. */
+int  spmv_host_jitter_columns(long m, long n, const int32_t * row_ptr, int32_t * col_idx, double * values, double frac, long span,
+		unsigned long seed);
+/* The graph partition of that matrix WITHOUT building it (breadth-first sweep and exchange volumes over columns computed on the
+ * fly): owner[m] in [0,parts) as spmv_host_bfs_order + spmv_host_owners_from_order give; volume[p] as spmv_host_partition_volume. */
+int  spmv_host_kkt_bfs_owner(long N, long parts, int32_t * owner);
+int  spmv_host_kkt_partition_volume(long N, const int32_t * owner, long parts, long * volume);
 /* x kept as `parts` slices padded to `padded` entries (one equal-sized allgather): column c of part p becomes
  * p*padded + (c - offsets[p]); offsets has parts+1 entries. In place. */
 int  spmv_host_remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, long padded);

@@ -19,23 +19,50 @@
 #include <omp.h>
 
 #include "host.hpp"
+#include "kkt_grid.hpp"
 #include "../csrc/host_threads.hpp"
 
 namespace spmv_host {
 
+// The graph is seen through an adjacency provider: row(v, buf, out) gives the neighbours of v — a pointer into the CSR for a
+// stored matrix, or columns computed on the fly for the analytic KKT matrix (kkt_grid.hpp), whose 28 M-vertex graph is then
+// partitioned without the 9 GB matrix ever being built.
+struct CsrAdj {
+	const int32_t * rp;
+	const int32_t * ci;
+	inline long row(long v, int32_t *, const int32_t *& out) const
+	{
+		out = ci + rp[v];
+		return rp[v + 1] - rp[v];
+	}
+};
+
+struct KktAdj {
+	Grid G;
+	inline long row(long v, int32_t * buf, const int32_t *& out) const
+	{
+		out = buf;
+		return kkt_row_cols(G, v, buf);
+	}
+};
+
 // one sweep from `start` over the vertices not yet marked; appends to order[tail...]; returns the new tail
+template <class Adj>
 static long
-sweep(const int32_t * rp, const int32_t * ci, long start, unsigned char * seen, int32_t * order, long tail)
+sweep(const Adj & adj, long start, unsigned char * seen, int32_t * order, long tail)
 {
 	long head = tail;
 	seen[start] = 1;
 	order[tail++] = (int32_t) start;
+	int32_t buf[64];
 	while (head < tail)
 	{
 		const long v = order[head++];
-		for (long j = rp[v]; j < rp[v + 1]; j++)
+		const int32_t * nb;
+		const long L = adj.row(v, buf, nb);
+		for (long j = 0; j < L; j++)
 		{
-			const int32_t c = ci[j];
+			const int32_t c = nb[j];
 			if (!seen[c])
 			{
 				seen[c] = 1;
@@ -46,6 +73,30 @@ sweep(const int32_t * rp, const int32_t * ci, long start, unsigned char * seen, 
 	return tail;
 }
 
+template <class Adj>
+static int
+bfs_order_t(const Adj & adj, long m, int32_t * order)
+{
+	if (m == 0)
+		return 0;
+	std::vector<unsigned char> seen((size_t) m, 0);
+	// the far end of a sweep from vertex 0 is (nearly) peripheral: sweeping from there gives thin, long level sets
+	long tail = sweep(adj, 0, seen.data(), order, 0);
+	const long far = order[tail - 1], first_component = tail;
+	for (long k = 0; k < first_component; k++)
+		seen[order[k]] = 0;
+	tail = sweep(adj, far, seen.data(), order, 0);
+	for (long v = 0; v < m && tail < m; v++)
+		if (!seen[v])
+			tail = sweep(adj, v, seen.data(), order, tail);
+	if (tail != m)
+	{
+		set_error("bfs_order: visited %ld of %ld vertices", tail, m);
+		return 1;
+	}
+	return 0;
+}
+
 int
 bfs_order(const int32_t * rp, const int32_t * ci, long m, long n, int32_t * order)
 {
@@ -54,24 +105,7 @@ bfs_order(const int32_t * rp, const int32_t * ci, long m, long n, int32_t * orde
 		set_error("bfs_order: the graph partition needs a square matrix (got %ld x %ld)", m, n);
 		return 1;
 	}
-	if (m == 0)
-		return 0;
-	std::vector<unsigned char> seen((size_t) m, 0);
-	// the far end of a sweep from vertex 0 is (nearly) peripheral: sweeping from there gives thin, long level sets
-	long tail = sweep(rp, ci, 0, seen.data(), order, 0);
-	const long far = order[tail - 1], first_component = tail;
-	for (long k = 0; k < first_component; k++)
-		seen[order[k]] = 0;
-	tail = sweep(rp, ci, far, seen.data(), order, 0);
-	for (long v = 0; v < m && tail < m; v++)
-		if (!seen[v])
-			tail = sweep(rp, ci, v, seen.data(), order, tail);
-	if (tail != m)
-	{
-		set_error("bfs_order: visited %ld of %ld vertices", tail, m);
-		return 1;
-	}
-	return 0;
+	return bfs_order_t(CsrAdj{rp, ci}, m, order);
 }
 
 int
@@ -95,8 +129,9 @@ owners_from_order(const int32_t * rp, long m, const int32_t * order, long parts,
 	return 0;
 }
 
-int
-partition_volume(const int32_t * rp, const int32_t * ci, long m, const int32_t * owner, long parts, long * volume)
+template <class Adj>
+static int
+partition_volume_t(const Adj & adj, long m, const int32_t * owner, long parts, long * volume)
 {
 	const long words = (m + 63) / 64;
 	std::vector<unsigned long long> bits((size_t) (parts * words), 0ull);
@@ -105,9 +140,12 @@ partition_volume(const int32_t * rp, const int32_t * ci, long m, const int32_t *
 	{
 		const long p = owner[i];
 		unsigned long long * b = bits.data() + p * words;
-		for (long j = rp[i]; j < rp[i + 1]; j++)
+		int32_t buf[64];
+		const int32_t * nb;
+		const long L = adj.row(i, buf, nb);
+		for (long j = 0; j < L; j++)
 		{
-			const long c = ci[j];
+			const long c = nb[j];
 			if (owner[c] != p)
 			{
 				const unsigned long long bit = 1ull << (c & 63);
@@ -126,6 +164,36 @@ partition_volume(const int32_t * rp, const int32_t * ci, long m, const int32_t *
 		volume[p] = cnt;
 	}
 	return 0;
+}
+
+int
+partition_volume(const int32_t * rp, const int32_t * ci, long m, const int32_t * owner, long parts, long * volume)
+{
+	return partition_volume_t(CsrAdj{rp, ci}, m, owner, parts, volume);
+}
+
+// ---- the same two steps for the analytic KKT matrix of edge N, matrix-free
+int
+kkt_bfs_owner(long N, long parts, int32_t * owner)
+{
+	KktAdj adj;
+	if (make_grid(N, adj.G))
+		return 1;
+	const long m = adj.G.n1 + adj.G.n2;
+	std::vector<int32_t> order((size_t) m), rp((size_t) m + 1);
+	long nnz = 0;
+	if (gen_kkt_row_ptr(N, rp.data(), nullptr, &nnz) || bfs_order_t(adj, m, order.data()))
+		return 1;
+	return owners_from_order(rp.data(), m, order.data(), parts, owner);
+}
+
+int
+kkt_partition_volume(long N, const int32_t * owner, long parts, long * volume)
+{
+	KktAdj adj;
+	if (make_grid(N, adj.G))
+		return 1;
+	return partition_volume_t(adj, adj.G.n1 + adj.G.n2, owner, parts, volume);
 }
 
 int

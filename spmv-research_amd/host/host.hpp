@@ -35,6 +35,10 @@ int gen_twin(long nr_rows, long nr_cols, double avg, double std, double bw_scale
 int gen_kkt(long N, unsigned long seed, spmv_host_csr * out);
 int gen_kkt_row_ptr(long N, int32_t * row_ptr, long * m_out, long * nnz_out);
 int gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out);
+int gen_kkt_rows(long N, unsigned long seed, const int32_t * rows, long count, spmv_host_csr * out);
+int jitter_columns(long m, long n, const int32_t * row_ptr, int32_t * col_idx, double * values, double frac, long span, unsigned long seed);
+int kkt_bfs_owner(long N, long parts, int32_t * owner);
+int kkt_partition_volume(long N, const int32_t * owner, long parts, long * volume);
 int column_ranges(const int32_t * col_idx, long nnz, long padded, long parts, long * lo, long * hi);
 int remap_columns(int32_t * col_idx, long nnz, const long * offsets, long parts, long padded);
 int bfs_order(const int32_t * rp, const int32_t * ci, long m, long n, int32_t * order);

@@ -149,6 +149,30 @@ spmv_host_bfs_order(const int32_t * row_ptr, const int32_t * col_idx, long m, lo
 }
 
 int
+spmv_host_gen_kkt_rows(long N, unsigned long seed, const int32_t * rows, long count, spmv_host_csr * out)
+{
+	return gen_kkt_rows(N, seed, rows, count, out);
+}
+
+int
+spmv_host_jitter_columns(long m, long n, const int32_t * row_ptr, int32_t * col_idx, double * values, double frac, long span, unsigned long seed)
+{
+	return jitter_columns(m, n, row_ptr, col_idx, values, frac, span, seed);
+}
+
+int
+spmv_host_kkt_bfs_owner(long N, long parts, int32_t * owner)
+{
+	return kkt_bfs_owner(N, parts, owner);
+}
+
+int
+spmv_host_kkt_partition_volume(long N, const int32_t * owner, long parts, long * volume)
+{
+	return kkt_partition_volume(N, owner, parts, volume);
+}
+
+int
 spmv_host_owners_from_order(const int32_t * row_ptr, long m, const int32_t * order, long parts, int32_t * owner)
 {
 	return owners_from_order(row_ptr, m, order, parts, owner);

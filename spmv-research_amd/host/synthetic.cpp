@@ -16,6 +16,7 @@
 #include <omp.h>
 
 #include "host.hpp"
+#include "kkt_grid.hpp"
 
 namespace spmv_host {
 
@@ -211,95 +212,6 @@ sym_value(uint64_t seed, long i, long j)
 	return (i == j) ? 4.0 : g.uniform(-1.0, 1.0);
 }
 
-struct Grid {
-	long N, N2, n1, n2, S;
-	inline int stencil7(long g, long * out) const      // in-bounds 7-point neighbours of g, ascending
-	{
-		long z = g / N2, y = (g / N) % N, x = g % N;
-		int k = 0;
-		if (z > 0) out[k++] = g - N2;
-		if (y > 0) out[k++] = g - N;
-		if (x > 0) out[k++] = g - 1;
-		out[k++] = g;
-		if (x < N - 1) out[k++] = g + 1;
-		if (y < N - 1) out[k++] = g + N;
-		if (z < N - 1) out[k++] = g + N2;
-		return k;
-	}
-	inline int stencil27(long g, long * out) const     // ascending
-	{
-		long z = g / N2, y = (g / N) % N, x = g % N;
-		int k = 0;
-		for (long dz = -1; dz <= 1; dz++)
-			for (long dy = -1; dy <= 1; dy++)
-				for (long dx = -1; dx <= 1; dx++)
-				{
-					long zz = z + dz, yy = y + dy, xx = x + dx;
-					if (zz < 0 || zz >= N || yy < 0 || yy >= N || xx < 0 || xx >= N)
-						continue;
-					out[k++] = zz * N2 + yy * N + xx;
-				}
-		return k;
-	}
-	inline long gk(long k) const { return k % n1; }                    // grid point of constraint row k
-	inline long w(long g) const { return (g + S) % n1; }               // half-domain shift
-	inline long winv(long g) const { return (g - S % n1 + n1) % n1; }
-	// columns of constraint row k (grid indices), ascending
-	inline int a_row(long k, long * out) const
-	{
-		long t[14];
-		int c = stencil7(gk(k), t);
-		c += stencil7(w(gk(k)), t + c);
-		std::sort(t, t + c);
-		c = (int) (std::unique(t, t + c) - t);
-		memcpy(out, t, c * sizeof(long));
-		return c;
-	}
-	// constraint rows k whose A-row touches grid point g, ascending
-	inline int a_col(long g, long * out) const
-	{
-		long h[14], t[28];
-		int c = stencil7(g, h);
-		long s7[7];
-		int c2 = stencil7(g, s7);
-		for (int q = 0; q < c2; q++)
-			h[c++] = winv(s7[q]);
-		// h: grid points p with g in stencil7(p) (symmetric) or g in stencil7(w(p))
-		int k = 0;
-		for (int q = 0; q < c; q++)
-		{
-			t[k++] = h[q];
-			if (h[q] + n1 < n2)
-				t[k++] = h[q] + n1;
-		}
-		std::sort(t, t + k);
-		k = (int) (std::unique(t, t + k) - t);
-		memcpy(out, t, k * sizeof(long));
-		return k;
-	}
-};
-
-static int
-make_grid(long N, Grid & G)
-{
-	if (N < 4)
-	{
-		set_error("KKT grid edge must be >= 4");
-		return 1;
-	}
-	G.N = N; G.N2 = N * N; G.n1 = N * N * N; G.n2 = G.n1 + 6 * N * N; G.S = G.n1 / 2 + N / 3;
-	return 0;
-}
-
-static inline int
-kkt_row_len(const Grid & G, long i)
-{
-	long tmp[32];
-	if (i < G.n1)
-		return G.stencil27(i, tmp) + G.a_col(i, tmp);
-	return G.a_row(i - G.n1, tmp);
-}
-
 // global row_ptr only (m+1 entries): lets every rank of a row-partitioned run find its block without building A
 int
 gen_kkt_row_ptr(long N, int32_t * row_ptr, long * m_out, long * nnz_out)
@@ -332,25 +244,35 @@ gen_kkt_row_ptr(long N, int32_t * row_ptr, long * m_out, long * nnz_out)
 	return 0;
 }
 
-// rows [r0,r1) of the KKT matrix as a local CSR (row_ptr starts at 0, columns global)
-int
-gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out)
+// the rows rows[0..lm) (or r0 .. r0+lm when rows == nullptr) of the KKT matrix as a local CSR (row_ptr starts at 0, columns global)
+static int
+gen_kkt_some(long N, unsigned long seed, const int32_t * rows, long r0, long lm, spmv_host_csr * out)
 {
 	memset(out, 0, sizeof(*out));
 	Grid G;
 	if (make_grid(N, G))
 		return 1;
 	const long m = G.n1 + G.n2;
-	if (r0 < 0 || r1 > m || r0 > r1)
+	auto row_of = [&](long li) { return rows ? (long) rows[li] : r0 + li; };
+	std::vector<int32_t> len((size_t) std::max<long>(lm, 1));
+	long bad = -1;
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 8192) reduction(max : bad)
+	for (long i = 0; i < lm; i++)
 	{
-		set_error("bad KKT row block [%ld,%ld) of %ld", r0, r1, m);
+		const long r = row_of(i);
+		if (r < 0 || r >= m)
+		{
+			bad = std::max(bad, i);
+			len[i] = 0;
+		}
+		else
+			len[i] = kkt_row_len(G, r);
+	}
+	if (bad >= 0)
+	{
+		set_error("KKT row list: entry %ld is outside [0,%ld)", bad, m);
 		return 1;
 	}
-	const long lm = r1 - r0;
-	std::vector<int32_t> len((size_t) std::max<long>(lm, 1));
-	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 8192)
-	for (long i = 0; i < lm; i++)
-		len[i] = kkt_row_len(G, r0 + i);
 	long nnz = 0;
 	for (long i = 0; i < lm; i++)
 		nnz += len[i];
@@ -367,28 +289,88 @@ gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out)
 	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 8192)
 	for (long li = 0; li < lm; li++)
 	{
-		const long i = r0 + li;
-		long tmp[32];
+		const long i = row_of(li);
 		int32_t * ci = out->col_idx + out->row_ptr[li];
 		double * va = out->values + out->row_ptr[li];
-		int k = 0;
-		if (i < G.n1)
-		{
-			int c = G.stencil27(i, tmp);
-			for (int q = 0; q < c; q++, k++)
-				ci[k] = (int32_t) tmp[q];
-			c = G.a_col(i, tmp);
-			for (int q = 0; q < c; q++, k++)
-				ci[k] = (int32_t) (G.n1 + tmp[q]);
-		}
-		else
-		{
-			int c = G.a_row(i - G.n1, tmp);
-			for (int q = 0; q < c; q++, k++)
-				ci[k] = (int32_t) tmp[q];
-		}
+		const int k = kkt_row_cols(G, i, ci);
 		for (int q = 0; q < k; q++)
 			va[q] = sym_value(seed, i, ci[q]);
+	}
+	return 0;
+}
+
+int
+gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out)
+{
+	Grid G;
+	if (make_grid(N, G))
+		return 1;
+	if (r0 < 0 || r1 > G.n1 + G.n2 || r0 > r1)
+	{
+		set_error("bad KKT row block [%ld,%ld) of %ld", r0, r1, G.n1 + G.n2);
+		return 1;
+	}
+	return gen_kkt_some(N, seed, nullptr, r0, r1 - r0, out);
+}
+
+int
+gen_kkt_rows(long N, unsigned long seed, const int32_t * rows, long count, spmv_host_csr * out)
+{
+	if (count < 0 || (count > 0 && !rows))
+	{
+		set_error("gen_kkt_rows: bad row list");
+		return 1;
+	}
+	return gen_kkt_some(N, seed, rows, 0, count, out);
+}
+
+// Perturb a generated matrix so that its column patterns stop being translation-invariant: in a fraction `frac` of the rows
+// every off-diagonal column moves by a random offset in [-span, span] (kept inside [0,n), kept off the diagonal, the row
+// re-sorted, collisions inside a row resolved by leaving the later entry where it was). Values stay attached to their
+// entries. Used to measure how much of the compressed-index SELL format's advantage is a property of the perfectly regular
+// twin (bench.py --jitter).
+int
+jitter_columns(long m, long n, const int32_t * row_ptr, int32_t * col_idx, double * values, double frac, long span, unsigned long seed)
+{
+	if (!(frac >= 0 && frac <= 1) || span < 1)
+	{
+		set_error("jitter_columns: frac must be in [0,1] and span >= 1");
+		return 1;
+	}
+	#pragma omp parallel num_threads(spmv::host_threads())
+	{
+		std::vector<std::pair<int32_t, double>> row;
+		#pragma omp for schedule(static, 4096)
+		for (long i = 0; i < m; i++)
+		{
+			Rng g(seed ^ 0x5EEDull, (uint64_t) i);
+			if (g.uniform() >= frac)
+				continue;
+			const long s0 = row_ptr[i], L = row_ptr[i + 1] - s0;
+			row.resize((size_t) L);
+			for (long k = 0; k < L; k++)
+				row[(size_t) k] = std::make_pair(col_idx[s0 + k], values[s0 + k]);
+			for (long k = 0; k < L; k++)
+			{
+				const int32_t c = row[(size_t) k].first;
+				if (c == i)
+					continue;
+				long nc = (long) c + g.below(2 * span + 1) - span;
+				if (nc < 0 || nc >= n || nc == i)
+					continue;
+				bool taken = false;
+				for (long q = 0; q < L && !taken; q++)
+					taken = q != k && row[(size_t) q].first == (int32_t) nc;
+				if (!taken)
+					row[(size_t) k].first = (int32_t) nc;
+			}
+			std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double> & a, const std::pair<int32_t, double> & b) { return a.first < b.first; });
+			for (long k = 0; k < L; k++)
+			{
+				col_idx[s0 + k] = row[(size_t) k].first;
+				values[s0 + k] = row[(size_t) k].second;
+			}
+		}
 	}
 	return 0;
 }

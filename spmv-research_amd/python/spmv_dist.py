@@ -145,6 +145,62 @@ def split_by_owner(blk, owner, rank):
     return out[0], out[1]
 
 
+def split_interior_boundary(blk, owner, rank):
+    """The rank's rows (a CSR in the rank's row order, ORIGINAL column numbers) reordered INTERIOR rows first (every column
+    owned by the rank: they can be computed while the halo is in flight), then BOUNDARY rows (at least one column owned by a
+    peer) — both groups keep their order and every row stays whole. Returns (order, split, interior CSR, boundary CSR):
+    order[k] = index in blk of the k-th row of the new order. Pure numpy on the rank's own block: no rank ever needs more of
+    the matrix than its rows."""
+    lm = int(blk["m"])
+    rp = np.asarray(blk["row_ptr"], np.int64)
+    ci, va = blk["col_idx"], blk["values"]
+    lens = np.diff(rp)
+    remote = (owner[ci] != rank)
+    per_row = np.zeros(lm, np.int64)
+    nz = np.flatnonzero(lens > 0)
+    if len(nz):
+        per_row[nz] = np.add.reduceat(remote.astype(np.int64), rp[:-1][nz])
+    is_b = per_row > 0
+    order = np.concatenate([np.flatnonzero(~is_b), np.flatnonzero(is_b)])
+    split = int((~is_b).sum())
+    ent_b = np.repeat(is_b, lens)                              # entry belongs to a boundary row
+    out = []
+    for rows_sel, ent_sel in ((~is_b, ~ent_b), (is_b, ent_b)):
+        l = lens[rows_sel]
+        r = np.zeros(len(l) + 1, np.int64)
+        np.cumsum(l, out=r[1:])
+        out.append(dict(m=int(len(l)), nnz=int(r[-1]), row_ptr=r.astype(np.int32), col_idx=np.ascontiguousarray(ci[ent_sel]),
+                        values=np.ascontiguousarray(va[ent_sel])))
+    return order, split, out[0], out[1]
+
+
+def recv_lists_from_block(blk, owner, rank, world):
+    """recv[q] = ascending original numbers of the x entries owned by q that this rank's rows read (from its own block only)."""
+    ci = blk["col_idx"]
+    n = len(owner)
+    touched = np.zeros(n, bool)
+    touched[ci] = True
+    cols = np.flatnonzero(touched)
+    own = owner[cols]
+    return [cols[own == q].astype(np.int32) if q != rank else np.zeros(0, np.int32) for q in range(world)]
+
+
+def exchange_send_lists(dist, torch, recv, rank, world, device):
+    """send[q] = what rank q asked for (its recv[rank]): one all_to_all of the list lengths, one of the lists themselves. The
+    matrix-free way to halo lists: spmv_host.halo_lists needs the whole matrix on every rank, this needs only the rank's rows."""
+    counts = torch.tensor([len(recv[q]) for q in range(world)], dtype=torch.int64, device=device)
+    got = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(got, counts)
+    got = [int(v) for v in got.cpu().numpy()]
+    flat = np.concatenate([np.asarray(r, np.int64) for r in recv]) if sum(len(r) for r in recv) else np.zeros(0, np.int64)
+    sendbuf = torch.from_numpy(flat).to(device)
+    recvbuf = torch.zeros(sum(got), dtype=torch.int64, device=device)
+    dist.all_to_all_single(recvbuf, sendbuf, got, [len(recv[q]) for q in range(world)])
+    arr = recvbuf.cpu().numpy().astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(got)])
+    return [arr[off[q]:off[q + 1]] for q in range(world)]
+
+
 class PackedExchange:
     """Halo exchange for the original-numbering layout: every rank keeps a full-length x in the matrix's ORIGINAL numbering
     (so its rows keep the column patterns the single-GPU format compresses), owns the entries of its vertices and receives

@@ -14,7 +14,8 @@ SYMBOLS = [
     "spmv_host_csr_free", "spmv_host_gen_twin", "spmv_host_gen_named", "spmv_host_gen_kkt", "spmv_host_csr_features",
     "spmv_host_gen_kkt_row_ptr", "spmv_host_gen_kkt_block", "spmv_host_remap_columns", "spmv_host_column_ranges",
     "spmv_host_bfs_order", "spmv_host_owners_from_order", "spmv_host_partition_volume", "spmv_host_partition_layout",
-    "spmv_host_permuted_block", "spmv_host_halo_lists",
+    "spmv_host_permuted_block", "spmv_host_halo_lists", "spmv_host_gen_kkt_rows", "spmv_host_jitter_columns",
+    "spmv_host_kkt_bfs_owner", "spmv_host_kkt_partition_volume",
 ]
 
 
@@ -160,6 +161,35 @@ def gen_kkt_block(N, r0, r1, seed=14):
     csr = _Csr()
     _check(lib().spmv_host_gen_kkt_block(C.c_long(N), C.c_ulong(seed), C.c_long(r0), C.c_long(r1), C.byref(csr)))
     return _take_csr(csr)
+
+
+def gen_kkt_rows(N, rows, seed=14):
+    """The rows `rows` (ascending or not) of the KKT matrix as a local CSR with global column indices."""
+    rows = np.ascontiguousarray(rows, np.int32)
+    csr = _Csr()
+    _check(lib().spmv_host_gen_kkt_rows(C.c_long(N), C.c_ulong(seed), _p(rows), C.c_long(len(rows)), C.byref(csr)))
+    return _take_csr(csr)
+
+
+def jitter_columns(A, frac, span=3, seed=14):
+    """In place on a CSR dict: perturb the off-diagonal columns of a fraction of the rows (bench.py --jitter)."""
+    assert A["col_idx"].dtype == np.int32 and A["values"].dtype == np.float64 and A["row_ptr"].dtype == np.int32
+    _check(lib().spmv_host_jitter_columns(C.c_long(A["m"]), C.c_long(A["n"]), _p(A["row_ptr"]), _p(A["col_idx"]), _p(A["values"]),
+                                          C.c_double(frac), C.c_long(span), C.c_ulong(seed)))
+    return A
+
+
+def kkt_bfs_owner(N, parts):
+    """owner[v] of the KKT matrix's breadth-first slab partition, computed without building the matrix."""
+    owner = np.zeros(kkt_size(N), np.int32)
+    _check(lib().spmv_host_kkt_bfs_owner(C.c_long(N), C.c_long(parts), _p(owner)))
+    return owner
+
+
+def kkt_partition_volume(N, owner, parts):
+    vol = np.zeros(parts, np.int64)
+    _check(lib().spmv_host_kkt_partition_volume(C.c_long(N), _p(_i32(owner)), C.c_long(parts), _p(vol)))
+    return vol
 
 
 def remap_columns(col_idx, offsets, padded):

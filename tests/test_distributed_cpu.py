@@ -160,3 +160,64 @@ def test_packed_halo_exchange_gloo(world, mode):
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) <= 1e-12
+
+
+def _halo_worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "spmv-research_amd", "python"),):
+        sys.path.insert(0, p)
+    import spmv_dist as D
+    import spmv_host as H
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N = 9
+        A = H.gen_kkt(N)                                           # the whole matrix: only to CHECK what the lean path computes
+        m = A["m"]
+        owner = H.kkt_bfs_owner(N, world)                          # matrix-free partition == the partition of the stored matrix
+        order = H.bfs_order(A["row_ptr"], A["col_idx"], m, m)
+        np.testing.assert_array_equal(owner, H.owners_from_order(A["row_ptr"], order, world))
+        np.testing.assert_array_equal(H.kkt_partition_volume(N, owner, world), H.partition_volume(A["row_ptr"], A["col_idx"], owner, world))
+        # the rank's rows, generated on their own
+        mine = np.flatnonzero(owner == rank).astype(np.int32)
+        blk = H.gen_kkt_rows(N, mine)
+        for k in (0, len(mine) // 2, len(mine) - 1):
+            r = mine[k]
+            np.testing.assert_array_equal(blk["col_idx"][blk["row_ptr"][k]:blk["row_ptr"][k + 1]], A["col_idx"][A["row_ptr"][r]:A["row_ptr"][r + 1]])
+            np.testing.assert_array_equal(blk["values"][blk["row_ptr"][k]:blk["row_ptr"][k + 1]], A["values"][A["row_ptr"][r]:A["row_ptr"][r + 1]])
+        # interior / boundary split from the rank's own block == the split computed from the whole matrix
+        order_r, split, interior, boundary = D.split_interior_boundary(blk, owner, rank)
+        ref = D.interior_boundary_blocks(A["row_ptr"], A["col_idx"], A["values"], owner, rank)
+        np.testing.assert_array_equal(mine[order_r], ref["rows"])
+        assert split == ref["split"]
+        for got, want in ((interior, ref["interior"]), (boundary, ref["boundary"])):
+            for key in ("row_ptr", "col_idx", "values"):
+                np.testing.assert_array_equal(got[key], want[key])
+        # halo lists: receive side from the own block, send side from ONE all_to_all of the receive lists == the lists from the whole matrix
+        recv = D.recv_lists_from_block(blk, owner, rank, world)
+        send = D.exchange_send_lists(dist, torch, recv, rank, world, torch.device("cpu"))
+        send_ref, recv_ref = H.halo_lists(A["row_ptr"], A["col_idx"], owner, world, rank)
+        for qq in range(world):
+            np.testing.assert_array_equal(recv[qq], recv_ref[qq])
+            np.testing.assert_array_equal(send[qq], send_ref[qq])
+        q.put((rank, "ok"))
+    except Exception as e:                                         # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL " + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_matrix_free_partition_and_halo_lists(world):
+    """What bench.py's N > 1 setup computes from a rank's OWN rows (matrix-free partition on the analytic KKT matrix, interior /
+    boundary split, receive lists, send lists through an all_to_all) equals what the whole-matrix routines give."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + world
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
