@@ -58,7 +58,7 @@ typedef struct {
 	int  lanes_per_row;     /* CSR_VECTOR: 2,4,8,16,32,64; 0 = chosen from mean nnz/row                            */
 	                        /* CSR_STREAM: the same field holds ROWS PER WAVEFRONT (4,8,16,32,64); 0 = auto          */
 	int  sell_split;        /* SELL delta format: wavefronts sharing one 64-row slice (1, 2 or 4); 0 = auto by slice count */
-	int  sell_c;            /* SELL: rows per slice (16, 32 or 64); 0 = 64 (one wavefront = one slice)             */
+	int  sell_c;            /* SELL: rows per slice (16, 32, 64, or 256 = the BSC library's, sell_c_s.cpp:58-60); 0 = 64         */
 	int  sell_sigma;        /* SELL: sort window in rows (multiple of sell_c); 0 = 16384 (sell_c_s.cpp:58-60)      */
 	int  merge_items;       /* MERGE: merge items per thread (5,7,9,11,13); COO: entries per lane (2,4,8); 0 = default */
 	int  xcd_remap;         /* tile order over the 8 XCDs: 0 = auto, 1 = contiguous work-balanced ranges, 2 = off,
@@ -92,6 +92,8 @@ typedef struct {
 	int  sell_window;       /* SELL, 64-row slices: a workgroup owns a group of consecutive slices, copies the group's column window of
 	                           x into LDS and gathers from there; column indices are 16-bit offsets into the window (for banded /
 	                           FEM matrices; csrc/kernels_sell_window.hip). 0 = auto (when every group's window fits), 1 = on, 2 = off */
+	int  kahan;             /* CSR_SCALAR: 1 = Kahan-compensated row sums, the reference's CUSTOM_KAHAN build (csr.cpp:353-373); same
+	                           operations in the same order -> bit-identical to it                                             */
 	int  sell_group;        /* sell_window: slices per workgroup (1, 2, 4, 8 or 16; times sell_split at most 16 wavefronts); 0 = auto */
 } spmv_mi355x_opts;
 
@@ -196,6 +198,32 @@ int  spmv_mi355x_pcg_dist(const spmv_mi355x_dist_ops * ops, int precision, long 
 int  spmv_mi355x_pbicgstab_dist(const spmv_mi355x_dist_ops * ops, int precision, long m_local, const int32_t * row_ptr_local,
 		const int32_t * col_idx_global, const double * values_fp64, const void * b_local_host, void * x_local_out_host,
 		long max_iterations, double * history_out, spmv_mi355x_solver_info * info);
+
+/* ---- several GPUs of one node behind ONE handle (SURVEY §8b "create_partitioned", §8e) ------------------------------------- */
+/* What the reference's single-process driver can call: csr_to_format() hands over the whole matrix (bench.cpp:600-603), the
+ * library cuts it into `nparts` nnz-balanced contiguous row blocks — loop_partitioner_balance_prefix_sums
+ * (lib/parallel_util.h:156-184, what csr.cpp:140 does per thread) with one worker per GPU — puts block p on devices[p]
+ * (NULL: device p modulo the device count) and keeps x on every device as nparts equal padded slices. Per SpMV the x slices
+ * are exchanged (RCCL allgather over xGMI; peer / device copies where RCCL is unavailable or several parts share a device)
+ * while each device computes the part of its block whose columns lie in its own slice; the remote-column part is accumulated
+ * once the exchange has landed. y comes back in global row order. Square matrices only.
+ * exchange: 0 = auto (RCCL when the devices are distinct and librccl.so.1 loads, else copies), 1 = RCCL, 2 = copies. */
+typedef struct spmv_mi355x_partitioned spmv_mi355x_partitioned;   /* opaque */
+int  spmv_mi355x_create_partitioned(spmv_mi355x_partitioned ** out, int nparts, const int * devices, int exchange, int format,
+		int precision, long m, long n, long nnz, const int32_t * row_ptr, const int32_t * col_idx, const double * values_fp64,
+		const spmv_mi355x_opts * opts /* may be NULL; device / row block / column filter fields are set per part */);
+int  spmv_mi355x_destroy_partitioned(spmv_mi355x_partitioned * P);
+/* Matrix_Format::spmv(x, y) with host buffers (n and m values of the handle's precision), same caching convention as
+ * spmv_mi355x_spmv: x is uploaded when its pointer is new, y is downloaded on the first call after an upload. */
+int  spmv_mi355x_spmv_partitioned(spmv_mi355x_partitioned * P, const void * x_host, void * y_host);
+int  spmv_mi355x_partitioned_set_always_copy(spmv_mi355x_partitioned * P, int on);
+/* `iters` SpMVs back to back on the resident x (exchange forced every time): wall-clock ms per SpMV between all-device syncs. */
+int  spmv_mi355x_time_partitioned(spmv_mi355x_partitioned * P, int iters, double * ms_per_iter_out);
+int  spmv_mi355x_partitioned_parts(const spmv_mi355x_partitioned * P);
+int  spmv_mi355x_partitioned_offsets(const spmv_mi355x_partitioned * P, long * offsets_out /* [nparts+1] */);
+const char * spmv_mi355x_partitioned_format_name(const spmv_mi355x_partitioned * P);
+const char * spmv_mi355x_partitioned_exchange(const spmv_mi355x_partitioned * P);     /* "RCCL allgather" | "peer copies" | ... */
+double spmv_mi355x_partitioned_mem_footprint(const spmv_mi355x_partitioned * P);
 
 /* ---- format introspection for parity tests (host copies of the converted arrays) -------------------------- */
 /* SELL-C-sigma layout: any out pointer may be NULL. Arrays are malloc'ed copies; free with spmv_mi355x_free().

@@ -90,6 +90,10 @@ typedef struct {
 int  orc_sell_sorted_build(const int32_t * row_ptr, const int32_t * col_idx, const double * values, long m, long nnz,
 		int C, int num_threads, int value_bytes, orc_sell_t * out);
 void orc_sell_free(orc_sell_t * s);
+/* the BSC SELL-C-sigma library's layout (sell_c_s.cpp:58-75, sell-C-s/RISC-V/sellcs_format.c:137-200, radix_sort.c:36-122):
+ * pinned bit for bit to the reference's own format code compiled in place (oracle/_ref/.../libref_sellcs.so) */
+long orc_sellcs_layout(const int32_t * row_ptr, const int32_t * col_idx, const double * values, long m, long C, long sigma,
+		int32_t * row_order, int32_t * widths, int64_t * slice_ptr, int32_t * col, double * val);
 void orc_sell_spmv_f64(const orc_sell_t * s, const double * x, double * y);
 void orc_sell_spmv_f32(const orc_sell_t * s, const float * x, float * y);
 

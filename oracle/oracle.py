@@ -192,6 +192,25 @@ class Sell:
             pass
 
 
+def sellcs_layout(row_ptr, col_idx, a, C_rows, sigma):
+    """The BSC SELL-C-sigma library's layout (orc_sellcs_layout): dict(row_order, widths, slice_ptr, col, val)."""
+    row_ptr, col_idx = _i32(row_ptr), _i32(col_idx)
+    a = np.ascontiguousarray(a, np.float64)
+    m = len(row_ptr) - 1
+    ns = (m + C_rows - 1) // C_rows
+    order = np.zeros(max(m, 1), np.int32)
+    widths = np.zeros(max(ns, 1), np.int32)
+    sp = np.zeros(ns + 1, np.int64)
+    L = lib()
+    L.orc_sellcs_layout.restype = C.c_long
+    args = (_p(row_ptr), _p(col_idx), _p(a), C.c_long(m), C.c_long(C_rows), C.c_long(sigma), _p(order), _p(widths), _p(sp))
+    total = L.orc_sellcs_layout(*args, None, None)
+    col = np.zeros(max(total, 1), np.int32)
+    val = np.zeros(max(total, 1), np.float64)
+    L.orc_sellcs_layout(*args, _p(col), _p(val))
+    return dict(row_order=order[:m], widths=widths[:ns], slice_ptr=sp, col=col[:total], val=val[:total])
+
+
 def csr_to_coo_rows(row_ptr):
     row_ptr = _i32(row_ptr)
     m = len(row_ptr) - 1

@@ -118,3 +118,30 @@ class RefBackend:
         med = self.lib.ref_time_spmv(x.ctypes, y.ctypes, C.c_long(min_loops), C.c_double(min_runtime),
                                      C.byref(loops), C.byref(tmin), C.byref(tmax))
         return dict(median=med, min=tmin.value, max=tmax.value, loops=loops.value)
+
+
+def sellcs_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "v3", "libref_sellcs.so"))
+
+
+def ref_sellcs_layout(row_ptr, col_idx, a, n_cols, C_rows, sigma):
+    """The reference's own SELL-C-sigma FORMAT code (sell-C-s/RISC-V/sellcs_format.c, radix_sort.c, sellcs_utils.c compiled in
+    place into oracle/_ref/v3/libref_sellcs.so) run on a CSR: dict(row_order, widths, slice_ptr, col, val)."""
+    L = C.CDLL(os.path.join(_HERE, "_ref", "v3", "libref_sellcs.so"), mode=C.RTLD_LOCAL)
+    L.ref_sellcs_convert.restype = C.c_long
+    row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+    col_idx = np.ascontiguousarray(col_idx, np.int32)
+    a = np.ascontiguousarray(a, np.float64)
+    m = len(row_ptr) - 1
+    ns = (m + C_rows - 1) // C_rows
+    order = np.zeros(max(m, 1), np.int32)
+    widths = np.zeros(max(ns, 1), np.int32)
+    sp = np.zeros(ns + 1, np.int64)
+    cap = int(C_rows) * int(np.sort(np.diff(row_ptr))[::-1][:max(ns, 1)].sum()) + C_rows       # sum of the ns longest rows bounds it
+    col = np.zeros(max(cap, 1), np.int32)
+    val = np.zeros(max(cap, 1), np.float64)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    total = L.ref_sellcs_convert(C.c_int32(m), C.c_int32(n_cols), p(row_ptr), p(col_idx), p(a), C.c_long(C_rows), C.c_long(sigma),
+                                 p(order), p(widths), p(sp), p(col), p(val), C.c_long(cap))
+    assert total <= cap
+    return dict(row_order=order[:m], widths=widths[:ns], slice_ptr=sp, col=col[:total], val=val[:total])

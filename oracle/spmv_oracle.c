@@ -715,3 +715,69 @@ orc_time_csr_spmv_f64(const int32_t * row_ptr, const int32_t * col_idx, const do
 	free(tt); free(i_s); free(i_e);
 	return med;
 }
+
+
+/* ---- the BSC SELL-C-sigma library's layout (row a7 of SURVEY §8a): benchmark_code/BENCH/src/spmv_kernels/sell_c_s.cpp:58-75 calls
+ * sellcs_init_params(C = 256, sigma = 16384) + sellcs_create_matrix_from_CSR_rd (sell-C-s/RISC-V/sellcs_format.c:205-226 ->
+ * csr_to_sellcs :137-200):
+ *   - row sizes (sellcs_utils.c:36-48), then per window of sigma rows an LSD radix sort by size, DESCENDING, paired with the row
+ *     ids (radix_sort.c:36-122: 4-bit digits, stable within equal sizes) -> row_order[sorted position] = original row;
+ *   - slice s = sorted rows [s*C, (s+1)*C); its width = size of its FIRST row (sellcs_format.c:150-158);
+ *   - values / column indices zero-initialised (:168-176) and written column-major: entry k of sorted row r at
+ *     slice_pointers[s] + k*C + (r % C) (:178-189); padding stays (column 0, value 0.0); the last slice of a matrix whose row
+ *     count is not a multiple of C keeps C lanes, the missing rows are all padding.
+ * Arrays are caller-allocated: row_order[m], widths[nslices], slice_ptr[nslices+1]; col/val may be NULL to query nnz_ext. */
+long
+orc_sellcs_layout(const int32_t * row_ptr, const int32_t * col_idx, const double * values, long m, long C, long sigma,
+		int32_t * row_order, int32_t * widths, int64_t * slice_ptr, int32_t * col, double * val)
+{
+	long nslices = (m + C - 1) / C, i, k, s;
+	for (i = 0; i < m; i++)
+		row_order[i] = (int32_t) i;
+	/* a stable descending sort by size inside each window (what the paired LSD radix sort produces) */
+	for (k = 0; k < m; k += sigma)
+	{
+		long e = k + sigma > m ? m : k + sigma, n = e - k, maxlen = 0, a;
+		for (i = k; i < e; i++)
+			if (row_ptr[i + 1] - row_ptr[i] > maxlen)
+				maxlen = row_ptr[i + 1] - row_ptr[i];
+		long * cnt = (long *) calloc((size_t) maxlen + 2, sizeof(long));
+		int32_t * tmp = (int32_t *) malloc((size_t) (n > 0 ? n : 1) * sizeof(int32_t));
+		for (i = k; i < e; i++)
+			cnt[maxlen - (row_ptr[i + 1] - row_ptr[i]) + 1]++;
+		for (a = 0; a <= maxlen; a++)
+			cnt[a + 1] += cnt[a];
+		for (i = k; i < e; i++)
+			tmp[cnt[maxlen - (row_ptr[i + 1] - row_ptr[i])]++] = (int32_t) i;
+		for (i = 0; i < n; i++)
+			row_order[k + i] = tmp[i];
+		free(cnt);
+		free(tmp);
+	}
+	slice_ptr[0] = 0;
+	for (s = 0; s < nslices; s++)
+	{
+		long first = row_order[s * C];
+		widths[s] = row_ptr[first + 1] - row_ptr[first];
+		slice_ptr[s + 1] = slice_ptr[s] + (int64_t) widths[s] * C;
+	}
+	if (col && val)
+	{
+		for (i = 0; i < slice_ptr[nslices]; i++)
+		{
+			col[i] = 0;
+			val[i] = 0.0;
+		}
+		for (i = 0; i < m; i++)
+		{
+			long o = row_order[i];
+			int64_t w = slice_ptr[i / C] + (i % C);
+			for (k = row_ptr[o]; k < row_ptr[o + 1]; k++, w += C)
+			{
+				col[w] = col_idx[k];
+				val[w] = values[k];
+			}
+		}
+	}
+	return (long) slice_ptr[nslices];
+}

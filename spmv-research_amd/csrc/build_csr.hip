@@ -324,7 +324,8 @@ build_csr_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int *
 	{
 		case SPMV_MI355X_CSR_SCALAR:
 			A->cfg.map = xcd_map_balanced(rp, lm, csr_scalar_rows_per_tile(), resolve_remap(A->remap, lm / csr_scalar_rows_per_tile()));
-			snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_SCALAR_%s", A->f32 ? "f" : "d");
+			A->cfg.kahan = o.kahan ? 1 : 0;
+			snprintf(A->format_name, sizeof(A->format_name), "MI355X_CSR_SCALAR%s_%s", o.kahan ? "_KAHAN" : "", A->f32 ? "f" : "d");
 			snprintf(A->kernel_name, sizeof(A->kernel_name), "csr_scalar_kernel");
 			return 0;
 		case SPMV_MI355X_CSR_STREAM:

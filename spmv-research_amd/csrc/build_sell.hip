@@ -13,7 +13,8 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 {
 	const long m = A->m;
 	const int C = A->sell_c;
-	const int TPR = WAVE / C;
+	const int TPR = C >= WAVE ? 1 : WAVE / C;            // lanes per row (C = 256: one workgroup per slice, one lane per row)
+	const long slices_per_tile = C > WAVE ? 1 : sell_slices_per_tile();
 	const long sigma = A->sell_sigma;
 	const long num_slices = (m + C - 1) / C;
 	std::vector<int> row_of_sorted(std::max<long>(m, 1));
@@ -88,8 +89,8 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 	}
 	A->sell_slices = num_slices;
 	A->sell_nnz_ext = nnz_ext;
-	A->cfg.map = xcd_map_balanced(slice_ptr.data(), num_slices, sell_slices_per_tile(),
-			resolve_remap(A->remap, (num_slices + sell_slices_per_tile() - 1) / sell_slices_per_tile()));
+	A->cfg.map = xcd_map_balanced(slice_ptr.data(), num_slices, slices_per_tile,
+			resolve_remap(A->remap, (num_slices + slices_per_tile - 1) / slices_per_tile));
 	if (dev_alloc(&A->d_slice_ptr, (size_t) num_slices + 1))
 		return 1;
 	HIP_TRY(hipMemcpy(A->d_slice_ptr, slice_ptr.data(), ((size_t) num_slices + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -325,8 +326,6 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 	const long num_slices = (m + C - 1) / C;
 	const long num_groups = (num_slices + NS - 1) / NS;
 	const long sigma = (long) NS * C;
-	if (m == 0 || A->nnz == 0)
-		return 2;
 	// ---- windows
 	std::vector<int> grp((size_t) num_groups * 4, 0);
 	long too_wide = 0;
@@ -440,9 +439,9 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 	// auto: one row per lane (C = 64, bit-exact) when there are enough slices to fill the chip several times over,
 	// else 16-row slices with 4 lanes per row (4x the wavefronts, 1/4 of the dependent chain) — profiles/sweep_r01.md
 	int C = o.sell_c ? o.sell_c : 64;
-	if (C != 16 && C != 32 && C != 64)
+	if (C != 16 && C != 32 && C != 64 && C != 256)
 	{
-		set_error("sell_c must be 16, 32 or 64 (got %d)", C);
+		set_error("sell_c must be 16, 32, 64 or 256 (got %d)", C);
 		return 1;
 	}
 	long sigma = o.sell_sigma ? o.sell_sigma : 16384;
@@ -472,14 +471,14 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 		return 1;
 	}
 	// ---- x window in LDS + 16-bit indices (banded / FEM matrices): sell_window 0 = auto, 1 = on (error when not applicable), 2 = off
-	if (C == 64 && o.sell_window != 2 && o.sell_delta != 2 && (o.sell_window == 1 || o.convert_on != 2))
+	if (C == 64 && o.sell_window != 2 && (o.sell_window == 1 || (o.sell_delta == 0 && o.convert_on == 0)))
 	{
 		const long slices = (lm + 63) / 64;
 		const double mean = lm > 0 ? (double) A->nnz / lm : 0;
 		// slices per workgroup: from sell_sigma when given, else enough groups for two per CU; waves per slice: enough wavefronts
 		// to occupy the chip when the matrix has few slices
 		int NS = o.sell_group ? o.sell_group : o.sell_sigma ? (int) std::min<long>(16, std::max<long>(1, sigma / 64)) : 0;
-		int S = o.sell_split ? o.sell_split : (slices >= 3072 ? 1 : slices >= 1536 ? 2 : 4);
+		int S = o.sell_split ? o.sell_split : (slices >= 8192 ? 1 : slices >= 2048 ? 2 : 4);      // pwtk twin (3 405 slices): 2 x 8 16.5 us, 1 x 16 16.2-19.7 us
 		if (NS == 0)
 			NS = 16 / S;          // 16 wavefronts per workgroup: measured best on the cant (4 x 4) and pwtk (16 x 1) twins — the window is
 			                      // copied once per workgroup, so fewer, larger groups copy less

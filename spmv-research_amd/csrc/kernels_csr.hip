@@ -18,7 +18,10 @@ namespace spmv {
 
 constexpr int CSR_BLOCK = 256;
 
-template <typename T, bool NT>
+// KAHAN: the reference's compensated variant (csr.cpp:353-373, -DCUSTOM_KAHAN): per element val = a*x - compensation (one FMA in
+// the reference build), tmp = sum + val, compensation = (tmp - sum) - val — the same operations in the same order, so y is
+// bit-identical to that build as well.
+template <typename T, bool NT, bool KAHAN>
 __global__ __launch_bounds__(CSR_BLOCK) void
 csr_scalar_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col, const T * __restrict__ val,
 		const T * __restrict__ x, T * __restrict__ y, int m, int beta, XcdMap map)
@@ -32,8 +35,22 @@ csr_scalar_kernel(const int * __restrict__ row_ptr, const int * __restrict__ col
 	int j = row_ptr[row];
 	int j_e = row_ptr[row + 1];
 	T sum = 0;
-	for (; j < j_e; j++)
-		sum = fma_t<T>(ld_stream<NT>(val + j), x[ld_stream<NT>(col + j)], sum);
+	if constexpr (KAHAN)
+	{
+		T compensation = 0;
+		for (; j < j_e; j++)
+		{
+			const T v = fma_t<T>(ld_stream<NT>(val + j), x[ld_stream<NT>(col + j)], -compensation);
+			const T tmp = sum + v;
+			compensation = (tmp - sum) - v;
+			sum = tmp;
+		}
+	}
+	else
+	{
+		for (; j < j_e; j++)
+			sum = fma_t<T>(ld_stream<NT>(val + j), x[ld_stream<NT>(col + j)], sum);
+	}
 	y[row] = beta ? y[row] + sum : sum;
 }
 
@@ -201,12 +218,19 @@ csr_scalar_dispatch(const int * row_ptr, const int * col, const void * val, cons
 		*grid_out = grid;
 	if (grid == 0)
 		return 0;
-	if (cfg.nt)
-		hipLaunchKernelGGL((csr_scalar_kernel<T, true>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col, (const T *) val,
-				(const T *) x, (T *) y, m, cfg.beta, cfg.map);
+	#define CSR_SCALAR_LAUNCH(NTV, K) hipLaunchKernelGGL((csr_scalar_kernel<T, NTV, K>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col, \
+			(const T *) val, (const T *) x, (T *) y, m, cfg.beta, cfg.map)
+	if (cfg.kahan)
+	{
+		if (cfg.nt) CSR_SCALAR_LAUNCH(true, true);
+		else        CSR_SCALAR_LAUNCH(false, true);
+	}
 	else
-		hipLaunchKernelGGL((csr_scalar_kernel<T, false>), dim3(grid), dim3(CSR_BLOCK), 0, stream, row_ptr, col, (const T *) val,
-				(const T *) x, (T *) y, m, cfg.beta, cfg.map);
+	{
+		if (cfg.nt) CSR_SCALAR_LAUNCH(true, false);
+		else        CSR_SCALAR_LAUNCH(false, false);
+	}
+	#undef CSR_SCALAR_LAUNCH
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

@@ -126,6 +126,43 @@ sell_kernel(const int64_t * __restrict__ slice_ptr, const int * __restrict__ col
 	}
 }
 
+// The BSC library's own slice height (sell_c_s.cpp:58-60: C = 256): one workgroup of 256 lanes = one slice, lane r owns sorted
+// row r of the slice and walks it left to right with one FMA per element (bit-identical to the sequential CSR loop, as C = 64).
+constexpr int SELL_WIDE_C = 256;
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(SELL_WIDE_C) void
+sell_wide_kernel(const int64_t * __restrict__ slice_ptr, const int * __restrict__ col, const T * __restrict__ val,
+		const int * __restrict__ row_of_sorted, const T * __restrict__ x, T * __restrict__ y,
+		int m, int num_slices, int beta, XcdMap map)
+{
+	constexpr int C = SELL_WIDE_C;
+	const unsigned slice = xcd_tile(blockIdx.x, map);
+	if (slice == NO_TILE || (int) slice >= num_slices)
+		return;
+	const int64_t p_e = slice_ptr[slice + 1];
+	int64_t p = slice_ptr[slice] + threadIdx.x;
+	T s = 0;
+	for (; p + 3 * C < p_e; p += 4 * C)
+	{
+		const int c0 = ld_stream<NT>(col + p), c1 = ld_stream<NT>(col + p + C), c2 = ld_stream<NT>(col + p + 2 * C), c3 = ld_stream<NT>(col + p + 3 * C);
+		const T v0 = ld_stream<NT>(val + p), v1 = ld_stream<NT>(val + p + C), v2 = ld_stream<NT>(val + p + 2 * C), v3 = ld_stream<NT>(val + p + 3 * C);
+		const T x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+		s = fma_t<T>(v0, x0, s);
+		s = fma_t<T>(v1, x1, s);
+		s = fma_t<T>(v2, x2, s);
+		s = fma_t<T>(v3, x3, s);
+	}
+	for (; p < p_e; p += C)
+		s = fma_t<T>(ld_stream<NT>(val + p), x[ld_stream<NT>(col + p)], s);
+	const long sorted_row = (long) slice * C + threadIdx.x;
+	if (sorted_row < m)
+	{
+		T * yp = y + row_of_sorted[sorted_row];
+		*yp = beta ? *yp + s : s;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ SELL-64-sigma-delta
 // Column indices are the only compressible stream of SpMV (values are data, x and y are compulsory). In a 64-row slice
 // the 64 lanes of step k hold neighbouring rows, and on banded / stencil / FEM matrices their columns sit within a few
@@ -414,13 +451,29 @@ static int
 sell_dispatch(int C, const int64_t * slice_ptr, const int * col, const void * val, const int * row_of_sorted, const void * x, void * y,
 		int m, int num_slices, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
+	if (C == SELL_WIDE_C)
+	{
+		const unsigned grid = xcd_grid(cfg.map);
+		if (grid_out)
+			*grid_out = grid;
+		if (grid == 0)
+			return 0;
+		if (cfg.nt)
+			hipLaunchKernelGGL((sell_wide_kernel<T, true>), dim3(grid), dim3(SELL_WIDE_C), 0, stream, slice_ptr, col, (const T *) val, row_of_sorted,
+					(const T *) x, (T *) y, m, num_slices, cfg.beta, cfg.map);
+		else
+			hipLaunchKernelGGL((sell_wide_kernel<T, false>), dim3(grid), dim3(SELL_WIDE_C), 0, stream, slice_ptr, col, (const T *) val, row_of_sorted,
+					(const T *) x, (T *) y, m, num_slices, cfg.beta, cfg.map);
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
 	switch (C)
 	{
 		case 16: return sell_launch_c<T, 16>(slice_ptr, col, val, row_of_sorted, x, y, m, num_slices, cfg, stream, grid_out);
 		case 32: return sell_launch_c<T, 32>(slice_ptr, col, val, row_of_sorted, x, y, m, num_slices, cfg, stream, grid_out);
 		case 64: return sell_launch_c<T, 64>(slice_ptr, col, val, row_of_sorted, x, y, m, num_slices, cfg, stream, grid_out);
 	}
-	set_error("sell: C must be 16, 32 or 64 (got %d)", C);
+	set_error("sell: C must be 16, 32, 64 or 256 (got %d)", C);
 	return 1;
 }
 

@@ -14,6 +14,7 @@ struct LaunchCfg {
 	int beta;           // 0: y = A x, 1: y += A x
 	int unit;           // merge path: every stored value equals unit_value (pattern matrices: 1.0) and the value array is not kept
 	double unit_value;
+	int kahan;          // csr_scalar: Kahan-compensated row sums (csr.cpp:353-373)
 };
 
 // tile geometry of each kernel family (units per workgroup), needed to build the XCD map

@@ -7,7 +7,11 @@
 // statistics_print_labels). The kernel family is chosen at compile time with -DSPMV_MI355X_FORMAT=<id> (one executable
 // per format, like every other backend) or at run time with the environment variable SPMV_MI355X_FORMAT
 // (csr_scalar | csr_vector | csr_merge | sell_c_sigma | coo | csr_stream); tunables via SPMV_MI355X_LANES_PER_ROW, _SELL_C,
-// _SELL_SIGMA, _SELL_DELTA, _SELL_SPLIT, _MERGE_ITEMS, _STREAM_MODE, _ROWS_PER_GROUP, _XCD_REMAP (the fields of spmv_mi355x_opts). Errors end the process the way the reference's error() does (lib/debug.h:83-135).
+// _SELL_SIGMA, _SELL_DELTA, _SELL_SPLIT, _SELL_WINDOW, _SELL_GROUP, _MERGE_ITEMS, _STREAM_MODE, _ROWS_PER_GROUP, _COL_BLOCKS, _XCD_REMAP
+// (the fields of spmv_mi355x_opts). SPMV_MI355X_NGPUS=N (N > 1) cuts the matrix into N nnz-balanced row blocks over the node's
+// GPUs behind the same Matrix_Format (spmv_mi355x_create_partitioned: RCCL allgather of x overlapped with the local columns);
+// SPMV_MI355X_EXCHANGE = 1 forces RCCL, 2 peer copies. Errors end the process the way the reference's error() does
+// (lib/debug.h:83-135).
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -53,9 +57,10 @@ chosen_format()
 struct MI355XFormat : Matrix_Format
 {
 	spmv_mi355x_matrix * handle;
+	spmv_mi355x_partitioned * parts;       // SPMV_MI355X_NGPUS > 1: the same matrix as row blocks on several GPUs
 
 	MI355XFormat(INT_T * row_ptr, INT_T * col_ind, ValueTypeReference * values, long m, long n, long nnz, int symmetric_input)
-		: Matrix_Format(m, n, nnz), handle(NULL)
+		: Matrix_Format(m, n, nnz), handle(NULL), parts(NULL)
 	{
 		spmv_mi355x_opts o;
 		memset(&o, 0, sizeof(o));
@@ -71,8 +76,23 @@ struct MI355XFormat : Matrix_Format
 		o.sell_delta = env_int("SPMV_MI355X_SELL_DELTA", 0);
 		o.sell_split = env_int("SPMV_MI355X_SELL_SPLIT", 0);
 		o.xcd_remap = env_int("SPMV_MI355X_XCD_REMAP", 0);
+		o.sell_window = env_int("SPMV_MI355X_SELL_WINDOW", 0);
+		o.sell_group = env_int("SPMV_MI355X_SELL_GROUP", 0);
 		o.symmetric_input = symmetric_input;
 		const int precision = (sizeof(ValueType) == 8) ? SPMV_MI355X_F64 : SPMV_MI355X_F32;
+		const int ngpus = env_int("SPMV_MI355X_NGPUS", 1);
+		if (ngpus > 1)
+		{
+			if (symmetric_input)
+				mi355x_error("SPMV_MI355X_NGPUS needs the expanded matrix (KEEP_SYMMETRY builds hand over one triangle)");
+			o.device = -1;
+			if (spmv_mi355x_create_partitioned(&parts, ngpus, NULL, env_int("SPMV_MI355X_EXCHANGE", 0), chosen_format(), precision, m, n, nnz,
+					row_ptr, col_ind, values, &o))
+				mi355x_error("%s", spmv_mi355x_last_error());
+			mem_footprint = spmv_mi355x_partitioned_mem_footprint(parts);
+			format_name = strdup(spmv_mi355x_partitioned_format_name(parts));
+			return;
+		}
 		// deep copy happens inside create(): the driver frees its CSR right after this call (bench.cpp:605-629)
 		if (spmv_mi355x_create(&handle, chosen_format(), precision, m, n, nnz, row_ptr, col_ind, values, &o))
 			mi355x_error("%s", spmv_mi355x_last_error());
@@ -84,7 +104,7 @@ struct MI355XFormat : Matrix_Format
 	// backend in the reference (csr_rocm_vector.cpp:224-257). CG/BiCG-style callers set SPMV_MI355X_ALWAYS_COPY=1.
 	void spmv(ValueType * x, ValueType * y)
 	{
-		if (spmv_mi355x_spmv(handle, x, y))
+		if (parts ? spmv_mi355x_spmv_partitioned(parts, x, y) : spmv_mi355x_spmv(handle, x, y))
 			mi355x_error("%s", spmv_mi355x_last_error());
 	}
 
@@ -100,7 +120,12 @@ csr_to_format(INT_T * row_ptr, INT_T * col_ind, ValueTypeReference * values, lon
 	// m/n/nnz/csr_mem_footprint stay those of the arrays the harness passed, as in the reference.
 	MI355XFormat * mf = new MI355XFormat(row_ptr, col_ind, values, m, n, nnz, (symmetric && !symmetry_expanded) ? 1 : 0);
 	if (env_int("SPMV_MI355X_ALWAYS_COPY", 0))
-		spmv_mi355x_set_always_copy(mf->handle, 1);
+	{
+		if (mf->parts)
+			spmv_mi355x_partitioned_set_always_copy(mf->parts, 1);
+		else
+			spmv_mi355x_set_always_copy(mf->handle, 1);
+	}
 	return mf;
 }
 

@@ -104,6 +104,20 @@ def _time_steps(dist, torch, fn, reps, warm=3):
     return _max_over_ranks(dist, torch, time.perf_counter() - t0) / reps * 1e3
 
 
+def _take_samples(blk, y_first, col_map=None, count=1000, seed=1):
+    """A few rows of a block kept for the sanity check (y index, global columns, values) so that the block itself can be freed."""
+    lm = int(blk["m"])
+    if lm == 0:
+        return []
+    rp, ci, va = blk["row_ptr"], blk["col_idx"], blk["values"]
+    out = []
+    for i in np.unique(np.random.default_rng(seed).integers(0, lm, count)):
+        a, e = int(rp[i]), int(rp[i + 1])
+        cols = ci[a:e].astype(np.int64)
+        out.append((y_first + int(i), cols if col_map is None else col_map(cols), va[a:e].copy()))
+    return out
+
+
 class RowsVariant:
     """BASELINE.json's scheme: contiguous nnz-balanced row blocks, allgather(x) (or, with --exchange p2p/auto, grouped send/recv of
     only the sub-ranges of each peer's slice that the block reads), local columns overlapped, remote columns accumulated."""
@@ -138,7 +152,10 @@ class RowsVariant:
         self.use_p2p, self.exch = False, None
         self.info = {"kind": "rows"}
         self.exchange_info = {"chosen": "allgather"}
+        self.lm = lm
+        self.samples = _take_samples(b, 0, self.col_map, 2000)
         self._validate()
+        self.blk = None                                   # the handles hold the matrix now: the host copy of the block goes
 
     def _fill_own(self):
         self.x_loc[:self.r1 - self.r0].copy_(self.ctx.torch.from_numpy(self.ctx.x_host[self.r0:self.r1]))
@@ -227,9 +244,6 @@ class RowsVariant:
         p = cols // self.padded
         return self.offsets[p] + (cols - p * self.padded)
 
-    def check_block(self):
-        return self.blk
-
     def describe(self):
         how = "send/recv of the needed x ranges" if self.use_p2p else "allgather(x)"
         return f"row-partitioned x{self.ctx.world} (row blocks of A), RCCL {how} " + \
@@ -257,8 +271,8 @@ class GraphVariant:
         self.rows = mine[order]
         self.split, self.lm = split, len(mine)
         recv = D.recv_lists_from_block(blk, owner, c.rank, c.world)
-        self.blk_check = blk                                              # rows in `mine` order: the sanity check maps through `order`
-        self.order = order
+        self.samples = _take_samples(interior, 0, None, 1000) + _take_samples(boundary, split, None, 1000, seed=2)
+        del blk                                                           # interior + boundary hold every row once
         self.t_gen = time.time() - t0
         dev = torch.device("cuda") if c.args.backend == "nccl" else torch.device("cpu")
         send = D.exchange_send_lists(dist, torch, recv, c.rank, c.world, dev)
@@ -298,9 +312,12 @@ class GraphVariant:
             self.launches = [(E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n, c.fmt, c.np_dtype, **c.opts), first, phase)
                              for b, first, phase in ((interior, 0, 0), (boundary, split, 1)) if b["m"] > 0]
         else:
+            del interior, boundary
             whole = c.src.rows(self.rows)
             self.launches = [(E.Matrix(whole["row_ptr"], whole["col_idx"], whole["values"], whole["m"], n, c.fmt, c.np_dtype, **c.opts), 0, 1)]
+            del whole
         self.mats = [l[0] for l in self.launches]
+        interior = boundary = None
         self.t_conv = time.time() - t0
         self.y = torch.full((self.lm + 64,), 1.0, dtype=c.t_dtype, device="cuda")
         self.exchange_info = {"chosen": "packed halo " + self.packed.mode, "recv_x_entries": self.packed.recv_elems,
@@ -328,15 +345,6 @@ class GraphVariant:
     def col_map(self, cols):
         return cols
 
-    def check_block(self):
-        """The rank's rows in the order of its y (interior first), as a CSR for the sampled-row check."""
-        b, order = self.blk_check, self.order
-        rp = np.asarray(b["row_ptr"], np.int64)
-        lens = np.diff(rp)[order]
-        nrp = np.zeros(len(order) + 1, np.int64)
-        np.cumsum(lens, out=nrp[1:])
-        return dict(m=len(order), row_ptr=nrp, col_idx=b["col_idx"], values=b["values"], row_start=rp[:-1][order])
-
     def describe(self):
         how = "all_to_all" if self.packed.mode == "alltoall" else "send/recv"
         return f"row-partitioned x{self.ctx.world} (breadth-first slabs of the matrix graph, x in original numbering), RCCL packed halo {how} " + \
@@ -346,7 +354,7 @@ class GraphVariant:
         for M in self.mats:
             M.close()
         self.mats, self.launches = [], []
-        self.x_full = self.y = self.packed = self.blk_check = None
+        self.x_full = self.y = self.packed = None
 
 
 class Ctx:
@@ -355,25 +363,14 @@ class Ctx:
 
 def _sampled_check(B, v, c):
     """Sampled rows of the rank's y against host dot products with the GLOBAL x (fp64)."""
-    yh = v.y[:v.lm if hasattr(v, "lm") else v.blk["m"]].cpu().numpy().astype(np.float64)
-    b = v.check_block()
-    lm = int(b["m"])
-    rp, ci, va = b["row_ptr"], b["col_idx"], b["values"]
-    starts = b.get("row_start")
-    samp = np.unique(np.random.default_rng(1).integers(0, max(lm, 1), 2000)) if lm > 0 else np.array([], np.int64)
+    yh = v.y[:v.lm].cpu().numpy().astype(np.float64)
     xg = c.x_host.astype(np.float64)
     worst = 0.0
-    for i in samp:
-        if starts is None:
-            a, e = int(rp[i]), int(rp[i + 1])
-        else:
-            a = int(starts[i])
-            e = a + int(rp[i + 1] - rp[i])
-        cols = v.col_map(ci[a:e].astype(np.int64))
-        vals = va[a:e].astype(c.np_dtype).astype(np.float64)
+    for yi, cols, vals in v.samples:
+        vals = vals.astype(c.np_dtype).astype(np.float64)
         ref = float(np.dot(vals, xg[cols]))
         den = float(np.dot(np.abs(vals), np.abs(xg[cols]))) or 1.0
-        worst = max(worst, abs(ref - float(yh[i])) / den)
+        worst = max(worst, abs(ref - float(yh[yi])) / den)
     tol = 1e-12 if c.dts == "f64" else 1e-5
     if not (worst <= tol) or not np.all(yh == yh):
         raise SystemExit(f"bench sanity check failed on rank {c.rank}: sampled rows differ from the host dot products (max {worst})")
@@ -403,7 +400,7 @@ def _measure(B, v, c, K, warmup):
     ms = elapsed / K * 1e3
     check = _sampled_check(B, v, c)
     lnnz = sum(M.nnz for M in v.mats)
-    lm = v.lm if hasattr(v, "lm") else v.blk["m"]
+    lm = v.lm
     return dict(ms_per_step=ms, stream_ms=stream_ms, comm_ms=comm_ms, kern_ms=kern_ms, check=check, lnnz=int(lnnz), lm=int(lm),
                 format_name=v.mats[0].format_name, kernel=v.mats[0].kernel_info()["name"])
 

@@ -27,7 +27,7 @@ class Opts(C.Structure):
                 ("row_begin", C.c_long), ("row_end", C.c_long), ("col_begin", C.c_long), ("col_end", C.c_long),
                 ("col_filter_mode", C.c_int), ("sell_delta", C.c_int), ("convert_on", C.c_int),
                 ("symmetric_input", C.c_int), ("rows_per_group", C.c_int), ("col_blocks", C.c_int),
-                ("sell_window", C.c_int), ("sell_group", C.c_int)]
+                ("sell_window", C.c_int), ("kahan", C.c_int), ("sell_group", C.c_int)]
 
 
 # every symbol declared in include/spmv_mi355x.h (checked by tests/test_abi.py)
@@ -40,6 +40,10 @@ SYMBOLS = [
     "spmv_mi355x_merge_tiles", "spmv_mi355x_free", "spmv_mi355x_precision", "spmv_mi355x_device",
     "spmv_mi355x_pcg", "spmv_mi355x_pbicgstab", "spmv_mi355x_pcg_dist", "spmv_mi355x_pbicgstab_dist",
     "spmv_mi355x_copy_device_async",
+    "spmv_mi355x_create_partitioned", "spmv_mi355x_destroy_partitioned", "spmv_mi355x_spmv_partitioned",
+    "spmv_mi355x_partitioned_set_always_copy", "spmv_mi355x_time_partitioned", "spmv_mi355x_partitioned_parts",
+    "spmv_mi355x_partitioned_offsets", "spmv_mi355x_partitioned_format_name", "spmv_mi355x_partitioned_exchange",
+    "spmv_mi355x_partitioned_mem_footprint",
 ]
 
 _lib = None
@@ -64,6 +68,9 @@ def lib():
         L.spmv_mi355x_csr_mem_footprint.restype = C.c_double
         for f in ("spmv_mi355x_rows", "spmv_mi355x_cols", "spmv_mi355x_nnz"):
             getattr(L, f).restype = C.c_long
+        L.spmv_mi355x_partitioned_format_name.restype = C.c_char_p
+        L.spmv_mi355x_partitioned_exchange.restype = C.c_char_p
+        L.spmv_mi355x_partitioned_mem_footprint.restype = C.c_double
         L.spmv_mi355x_x_device.restype = C.c_void_p
         L.spmv_mi355x_y_device.restype = C.c_void_p
         _lib = L
@@ -132,6 +139,62 @@ def solve_distributed(method, ops, dtype, m_local, row_ptr, col_idx, values, b, 
     out["x"] = x[:m_local]
     out["history"] = hist[:info.iterations] if history else None
     return out
+
+
+class PartitionedMatrix:
+    """One matrix cut into nnz-balanced row blocks over several GPUs of one node behind ONE handle
+    (spmv_mi355x_create_partitioned): what the reference's single-process driver would hold as its Matrix_Format."""
+
+    def __init__(self, row_ptr, col_idx, values, m, n, nparts, fmt="sell_c_sigma", dtype=np.float64, devices=None, exchange=0, **opts):
+        row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+        col_idx = np.ascontiguousarray(col_idx, np.int32)
+        values = np.ascontiguousarray(values, np.float64)
+        self.dtype = np.dtype(dtype)
+        o = Opts()
+        o.struct_size = C.sizeof(Opts)
+        o.device = -1
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(o, k, v)
+        dev = None if devices is None else np.ascontiguousarray(devices, np.int32)
+        self.h = C.c_void_p()
+        fmt_id = FORMATS[fmt] if isinstance(fmt, str) else fmt
+        _check(lib().spmv_mi355x_create_partitioned(C.byref(self.h), C.c_int(nparts), None if dev is None else _p(dev), C.c_int(exchange),
+                                                    fmt_id, F64 if self.dtype == np.float64 else F32, C.c_long(m), C.c_long(n),
+                                                    C.c_long(len(col_idx)), _p(row_ptr), _p(col_idx), _p(values), C.byref(o)))
+        L = lib()
+        self.m, self.n, self.nparts = m, n, L.spmv_mi355x_partitioned_parts(self.h)
+        self.format_name = L.spmv_mi355x_partitioned_format_name(self.h).decode()
+        self.exchange = L.spmv_mi355x_partitioned_exchange(self.h).decode()
+        self.mem_footprint = L.spmv_mi355x_partitioned_mem_footprint(self.h)
+        off = np.zeros(self.nparts + 1, np.int64)
+        _check(L.spmv_mi355x_partitioned_offsets(self.h, _p(off)))
+        self.offsets = off
+
+    def spmv(self, x, always_copy=True):
+        x = np.ascontiguousarray(x, self.dtype)
+        assert x.shape[0] == self.n
+        y = np.ones(self.m + 64, self.dtype)
+        lib().spmv_mi355x_partitioned_set_always_copy(self.h, 1 if always_copy else 0)
+        _check(lib().spmv_mi355x_spmv_partitioned(self.h, _p(x), _p(y)))
+        return y[:self.m].copy()
+
+    def time(self, iters):
+        ms = C.c_double()
+        _check(lib().spmv_mi355x_time_partitioned(self.h, C.c_int(iters), C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().spmv_mi355x_destroy_partitioned(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Matrix:

@@ -22,7 +22,8 @@ def kernel_means(d):
                 k = r["Kernel_Name"]
                 # the SpMV kernels only: not the fix-up / search / expansion helpers, not the conversion kernels
                 if "spmv::" not in k or not any(t in k for t in ("csr_scalar_kernel", "csr_vector_kernel", "csr_vector_multi_kernel",
-                        "csr_stream", "csr_window_kernel", "merge_kernel", "sell_kernel", "sell_delta", "coo_kernel", "coo_blocked_kernel")):
+                        "csr_stream", "csr_window_kernel", "merge_kernel", "sell_kernel", "sell_delta", "sell_window_kernel", "sell_wide_kernel",
+                        "coo_kernel", "coo_blocked_kernel")):
                     continue
                 name = k.split("(")[0].replace("void spmv::", "")
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -62,17 +63,19 @@ def main():
                    counters={k: v for k, v in m.items() if not k.startswith("_")})
         records.append(rec)
         print(tag, rec["kernel"], "read %.3f GB (2xFETCH %.3f GB) write %.3f GB" % (read_bytes / 1e9, rec["read_bytes_2x_fetch_size"] / 1e9, write_bytes / 1e9))
-    # workload/format/dtype keys for bench.py: filled from a side file written next to the passes
+    # what ran (tools/run_one.py --meta): bench.py attaches a record only to the same kernel, format name and kernel sources
     for rec in records:
-        w, rest = rec["tag"].split("_", 1)
-        for wl in ("soc-LiveJournal1", "nlpkkt240", "scircuit", "cant", "pwtk"):
-            if rec["tag"].startswith(wl + "_"):
-                w, rest = wl, rec["tag"][len(wl) + 1:]
-        for fmt in ("csr_scalar", "csr_vector", "csr_stream", "csr_merge", "sell_c_sigma", "coo"):
-            if rest.startswith(fmt):
-                rec["workload"], rec["format"] = w, fmt
-                rec["dtype"] = "f32" if "_f32" in rest else "f64"
-                rec["opts"] = rest[len(fmt):].replace("_f64", "").replace("_f32", "").strip("_")
+        meta = os.path.join(root, rec["tag"], "meta.json")
+        if os.path.exists(meta):
+            with open(meta) as fh:
+                m = json.load(fh)
+            rec.update(workload=m["workload"], format=m["format"], dtype=m["dtype"], opts=m["opts"], scale=m.get("scale", 1.0),
+                       format_name=m["format_name"], kernel_src_sha=m["kernel_src_sha"], algorithmic_bytes=m["algorithmic_bytes"],
+                       us_per_launch_unprofiled=m["us_per_launch"])
+            rec["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_launch"] / m["algorithmic_bytes"], 4)
+            hit, miss = rec["counters"].get("TCC_HIT_sum"), rec["counters"].get("TCC_MISS_sum")
+            if hit is not None and miss:
+                rec["l2_hit_rate"] = round(hit / (hit + miss), 4)
     with open(outp, "w") as f:
         json.dump(dict(records=records), f, indent=1)
 

@@ -6,6 +6,8 @@ for spec in $1; do
   IFS=: read wl fmt dt opts <<< "$spec"
   optstr=""; for o in $(echo $opts | tr ',' ' '); do optstr="$optstr --opt $o"; done
   tag=$(echo $spec | tr ':,=' '___')
+  mkdir -p gpurun_out/traffic/$tag
+  timeout -k 5 300 python tools/run_one.py --workload $wl --format $fmt --dtype $dt $optstr --iters 50 --meta gpurun_out/traffic/$tag/meta.json > gpurun_out/traffic_${tag}_meta.log 2>&1
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[], help="key=value")
+    ap.add_argument("--meta", default="", help="write what ran (format name, kernel, kernel-source fingerprint) to this JSON file")
     args = ap.parse_args()
     import torch
     import spmv_host as H
@@ -38,6 +39,14 @@ def main():
     vb = 8 if args.dtype == "f64" else 4
     B = A["nnz"] * (vb + 4) + (A["m"] + 1) * 4 + (A["n"] + A["m"]) * vb
     print(f"{args.workload} {M.format_name} {ms*1e3:.1f} us/launch {B/ms/1e6:.1f} GB/s algorithmic_bytes={B}")
+    if args.meta:
+        import json
+        sys.path.insert(0, ROOT)
+        import bench
+        os.makedirs(os.path.dirname(args.meta), exist_ok=True)
+        with open(args.meta, "w") as f:
+            json.dump(dict(workload=args.workload, dtype=args.dtype, format=args.format, opts=opts, scale=args.scale, format_name=M.format_name,
+                           kernel=M.kernel_info()["name"], kernel_src_sha=bench.kernel_source_sha(), algorithmic_bytes=B, us_per_launch=ms * 1e3), f)
 
 
 if __name__ == "__main__":
