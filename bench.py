@@ -79,6 +79,9 @@ def parse(argv=None):
                     help="nlpkkt240 only: fraction of rows whose off-diagonal columns are perturbed by up to +-jitter-span "
                          "(sensitivity of the compressed-index format to the twin's regularity; invalid as the headline)")
     ap.add_argument("--jitter-span", type=int, default=3)
+    ap.add_argument("--index-modes-off", type=int, default=0,
+                    help="SELL delta layout, sensitivity experiment: 1 = no affine slices, 2 = no per-slice lane offsets, 3 = neither "
+                         "(every slice stores 8/16-bit deltas per lane); invalid as the headline")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
                     help="time configs 1-4 (named + best kernel) after the headline; auto = on for the default headline at N = 1")
     ap.add_argument("--configs-steps", type=int, default=300)
@@ -441,6 +444,8 @@ def main():
     dts = args.dtype or DEFAULT_DTYPE.get(workload, "f64")
     opts = collect_opts(args, workload)
 
+    if args.index_modes_off:
+        os.environ["SPMV_MI355X_SELL_MODES_OFF"] = str(args.index_modes_off)
     t0 = time.time()
     A, data = load_workload(H, workload, args.scale, args.jitter, args.jitter_span)
     t_gen = time.time() - t0
@@ -453,6 +458,8 @@ def main():
     wl = f"{workload} ({'synthetic twin' if data == 'synthetic' else data})" + ("" if args.scale == 1.0 else f" scale={args.scale}")
     if args.jitter:
         wl += f" jitter={args.jitter}x+-{args.jitter_span}"
+    if args.index_modes_off:
+        wl += f" index-modes-off={args.index_modes_off}"
     result = {
         "metric": f"GFLOP/s (2*nnz/t, {'fp64' if dts == 'f64' else 'fp32'} SpMV y=A*x); achieved HBM GB/s and % of peak in 'roofline'",
         "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -463,7 +470,7 @@ def main():
                    "parallelism": "single GPU", "stored_bytes_per_nnz": round(t["mem_footprint"] / max(nnz, 1), 3)},
         "hbm_gbps_algorithmic": round(B_alg / (ms_per_step * 1e-3) / 1e9, 2),
         "hbm_pct_of_peak": round(100.0 * B_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 2),
-        "roofline": roofline_record(workload, dts, t, with_traffic=args.scale == 1.0 and not args.jitter),
+        "roofline": roofline_record(workload, dts, t, with_traffic=args.scale == 1.0 and not args.jitter and not args.index_modes_off),
         "check_max_err_over_abs_row": t["check"],
         "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t["convert_s"], 2)},
     }
@@ -471,7 +478,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, workload, dts, A, t["x_host"], t["yh"])
     del A, t
     want_configs = args.configs == "on" or (args.configs == "auto" and workload == "nlpkkt240" and args.format is None
-                                            and args.scale == 1.0 and not args.jitter)
+                                            and args.scale == 1.0 and not args.jitter and not args.index_modes_off)
     if want_configs:
         result["configs"] = run_small_configs(E, torch, H, args)
     print(json.dumps(result), flush=True)

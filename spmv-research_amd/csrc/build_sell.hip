@@ -205,7 +205,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 			if (hi >= 0)
 				maxdelta = std::max<long>(maxdelta, (long) hi - lo);
 		}
-		const int md = affine ? 0 : rowoff ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		const int md = (affine && !(sell_modes_off() & 1)) ? 0 : (rowoff && !(sell_modes_off() & 2)) ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
 		mode[sl] = (unsigned char) md;
 		val_ptr[sl + 1] = maxlen * C;                    // values: exact width; index groups: rounded up to 4 steps
 		idx_ptr[sl + 1] = (md == 3 ? 4 * C : 0) + (width / 4) * ((md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024);

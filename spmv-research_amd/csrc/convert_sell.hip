@@ -66,7 +66,7 @@ group_bytes(int md)
 // pass 1: one wave per slice -> mode, number of value slots, number of index bytes
 __global__ __launch_bounds__(CV_BLOCK) void
 slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, const int * __restrict__ row_of_sorted, long m, long n,
-		long num_slices, unsigned char * __restrict__ mode, int64_t * __restrict__ val_count, int64_t * __restrict__ idx_count)
+		long num_slices, unsigned char * __restrict__ mode, int64_t * __restrict__ val_count, int64_t * __restrict__ idx_count, int modes_off)
 {
 	const long sl = ((long) blockIdx.x * CV_BLOCK + threadIdx.x) / WAVE;
 	const int lane = threadIdx.x % WAVE;
@@ -113,7 +113,8 @@ slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, con
 		affine = (uniform && maxlen == 0) ? 1 : 0;
 	if (lane == 0)
 	{
-		const int md = affine ? 0 : rowoff ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		// modes_off (sensitivity experiments, sell_modes_off()): bit 0 forbids the affine mode, bit 1 the per-slice lane offsets
+		const int md = (affine && !(modes_off & 1)) ? 0 : (rowoff && !(modes_off & 2)) ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
 		mode[sl] = (unsigned char) md;
 		val_count[sl] = (int64_t) maxlen * WAVE;             // values: exact width; index groups: rounded up to 4 steps
 		idx_count[sl] = (int64_t) (md == 3 ? 4 * WAVE : 0) + (int64_t) (width / 4) * group_bytes(md);
@@ -291,7 +292,7 @@ sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, c
 	if (num_slices > 0)
 	{
 		hipLaunchKernelGGL(slice_shape_kernel, dim3(slice_grid), dim3(CV_BLOCK), 0, 0, rp, ci, row_of_sorted, m, n_cols, num_slices, mode,
-				val_count, idx_count);
+				val_count, idx_count, sell_modes_off());
 		HIP_TRY(hipGetLastError());
 	}
 	{

@@ -24,7 +24,8 @@ typedef unsigned sellw_uint2 __attribute__((ext_vector_type(2)));
 
 // One or two index groups (4 steps each) of one lane: an 8-byte index load + 4 value loads per group, all issued before the
 // first LDS read. Values and indices are both padded to whole groups (<= 3 zero steps per slice), so every group is full.
-// (A deeper batch of 4 groups with clamped re-loads for short tails was measured slower: cant twin 10.2 vs 9.6 us.)
+// (Measured slower on the same twins: a deeper batch of 4 groups with clamped re-loads for short tails — cant 10.2 vs 9.6 us; all
+// of a wave's first 6 groups loaded up front behind wave-uniform branches — cant 10.0 vs 9.3 us, pwtk fp32 18.1 vs 16.5 us.)
 template <typename T>
 struct SellwPair {
 	sellw_uint2 d0, d1;

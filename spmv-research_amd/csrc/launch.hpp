@@ -73,6 +73,15 @@ int launch_sell_window(bool f32, int waves_per_slice, int slices_per_group, cons
 		const void * val, const int * row_of_sorted, const void * x, void * y, int m, int lds_window_bytes, const LaunchCfg & cfg,
 		hipStream_t stream, long * grid_out);
 
+// Sensitivity experiments on the delta layout's index-free modes: SPMV_MI355X_SELL_MODES_OFF, bit 0 = no affine slices (mode 0),
+// bit 1 = no per-slice lane offsets (mode 3); such slices then store 8- / 16-bit deltas per lane. Read at every create().
+inline int
+sell_modes_off()
+{
+	const char * e = getenv("SPMV_MI355X_SELL_MODES_OFF");
+	return e ? atoi(e) & 3 : 0;
+}
+
 // CSR -> SELL-64-sigma-delta on the GPU (convert_sell.hip); outputs are device arrays owned by the caller
 int sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
 		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,

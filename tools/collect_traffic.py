@@ -69,6 +69,10 @@ def main():
         if os.path.exists(meta):
             with open(meta) as fh:
                 m = json.load(fh)
+            if m.get("jitter") or m.get("modes_off"):
+                rec["variant"] = {"jitter": m.get("jitter", 0.0), "index_modes_off": m.get("modes_off", 0)}      # never matches a bench line
+                m["scale"] = -1.0
+            rec["stored_bytes_per_nnz"] = round(m.get("stored_bytes_per_nnz", 0.0), 4)
             rec.update(workload=m["workload"], format=m["format"], dtype=m["dtype"], opts=m["opts"], scale=m.get("scale", 1.0),
                        format_name=m["format_name"], kernel_src_sha=m["kernel_src_sha"], algorithmic_bytes=m["algorithmic_bytes"],
                        us_per_launch_unprofiled=m["us_per_launch"])

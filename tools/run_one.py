@@ -18,12 +18,16 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[], help="key=value")
+    ap.add_argument("--jitter", type=float, default=0.0, help="fraction of rows whose off-diagonal columns are perturbed by +-jitter-span")
+    ap.add_argument("--jitter-span", type=int, default=3)
     ap.add_argument("--meta", default="", help="write what ran (format name, kernel, kernel-source fingerprint) to this JSON file")
     args = ap.parse_args()
     import torch
     import spmv_host as H
     import spmv_mi355x as E
     A = H.gen_named(args.workload, args.scale)
+    if args.jitter:
+        H.jitter_columns(A, args.jitter, args.jitter_span)
     npd = np.float64 if args.dtype == "f64" else np.float32
     td = torch.float64 if args.dtype == "f64" else torch.float32
     opts = {k: int(v) for k, v in (o.split("=") for o in args.opt)}
@@ -45,7 +49,9 @@ def main():
         import bench
         os.makedirs(os.path.dirname(args.meta), exist_ok=True)
         with open(args.meta, "w") as f:
-            json.dump(dict(workload=args.workload, dtype=args.dtype, format=args.format, opts=opts, scale=args.scale, format_name=M.format_name,
+            json.dump(dict(workload=args.workload, dtype=args.dtype, format=args.format, opts=opts, scale=args.scale, jitter=args.jitter,
+                           modes_off=int(os.environ.get("SPMV_MI355X_SELL_MODES_OFF", "0")), stored_bytes_per_nnz=M.mem_footprint / max(A["nnz"], 1),
+                           format_name=M.format_name,
                            kernel=M.kernel_info()["name"], kernel_src_sha=bench.kernel_source_sha(), algorithmic_bytes=B, us_per_launch=ms * 1e3), f)
 
 
