@@ -40,7 +40,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI3
 INFINITY_CACHE_BYTES = 256 << 20
 WORKLOADS = ("cant", "scircuit", "pwtk", "soc-LiveJournal1", "nlpkkt240")
 # the engine's best kernel per workload (what `bench.py --workload W` times when --format is not given)
-DEFAULT_FORMAT = {"nlpkkt240": "sell_c_sigma", "cant": "csr_stream", "pwtk": "csr_stream",
+DEFAULT_FORMAT = {"nlpkkt240": "sell_c_sigma", "cant": "sell_c_sigma", "pwtk": "csr_stream",
                   "scircuit": "csr_vector", "soc-LiveJournal1": "coo"}
 DEFAULT_DTYPE = {"pwtk": "f32"}
 # options that go with a default format (only when --format is not given)

@@ -131,6 +131,11 @@ int  spmv_host_halo_lists(const int32_t * row_ptr, const int32_t * col_idx, long
  * 596-695,961): out[0..6] = avg nnz/row, std nnz/row, avg bandwidth scaled by n, skew = (max-avg)/avg,
  * avg_num_neighbours (window 1), cross_row_similarity (window 1), max nnz/row. */
 int  spmv_host_csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out7);
+/* The matrix statistics of the reference's artificial-matrix CSV row (bench_spmv.cpp:489-563): out15 = density [%], mem_footprint
+ * [MiB, fp64 CSR], avg/std nnz per row, avg/std bandwidth, the same scaled by n, avg/std scatter (degree / bandwidth), the same for
+ * the scaled bandwidth, skew, avg_num_neighbours, cross_row_similarity; mem_range = the power-of-two class "[lo-hi]" in MiB. */
+int  spmv_host_csr_am_stats(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out15, char * mem_range,
+		long mem_range_n);
 
 #ifdef __cplusplus
 }

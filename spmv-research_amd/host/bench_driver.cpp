@@ -57,6 +57,10 @@ static const char * SOLVER_LABELS =      // bench_cg.cpp:423-440
 	"matrix_name,num_threads,csr_m,csr_n,csr_nnz,time,error,num_iterations,csr_mem_footprint,W_avg,J_estimated,"
 	"format_name,m,n,nnz,mem_footprint,mem_ratio";
 
+static const char * AM_LABELS =          // bench_spmv.cpp:493-522 (artificial-matrix mode)
+	"matrix_name,distribution,placement,seed,nr_rows,nr_cols,nr_nzeros,density,mem_footprint,mem_range,avg_nnz_per_row,std_nnz_per_row,"
+	"avg_bw,std_bw,avg_bw_scaled,std_bw_scaled,avg_sc,std_sc,avg_sc_scaled,std_sc_scaled,skew,avg_num_neighbours,cross_row_similarity,"
+	"format_name,time,gflops,W_avg,J_estimated";
 static const char * LABELS =
 	"matrix_name,num_threads,csr_m,csr_n,csr_nnz,symmetry,time,time_iter_min,time_iter_median,time_iter_max,gflops,"
 	"csr_mem_footprint,W_avg,J_estimated,format_name,m,n,nnz,mem_footprint,mem_ratio,num_loops,"
@@ -140,9 +144,12 @@ main(int argc, char ** argv)
 		argv++;
 		argc--;
 	}
+	// USE_ARTIFICIAL_MATRICES=1 (config.sh conf_vars; bench.cpp:497): argv holds the generator's feature vector instead of a file
+	// name (bench.cpp:569-579) and the CSV row / label line are the synthetic-dataset ones (bench_spmv.cpp:489-563)
+	const int use_artificial = env_int("USE_ARTIFICIAL_MATRICES", 0);
 	if (argc == 1)
 	{
-		fprintf(stderr, "%s\n", solver ? SOLVER_LABELS : LABELS);
+		fprintf(stderr, "%s\n", solver ? SOLVER_LABELS : use_artificial ? AM_LABELS : LABELS);
 		return 0;
 	}
 
@@ -153,7 +160,50 @@ main(int argc, char ** argv)
 	char matrix_name[1000];
 	double t;
 
-	if (!strcmp(argv[1], "--twin"))
+	double am[15] = {0};
+	char am_range[32] = "", am_distribution[64] = "", am_placement[64] = "";
+	long am_seed = 0;
+	if (use_artificial && strcmp(argv[1], "--twin"))
+	{
+		// nr_rows nr_cols avg_nnz_per_row std_nnz_per_row distribution placement avg_bw skew avg_num_neighbours cross_row_similarity seed
+		// [matrix_name]. The reference's generator is an un-vendored submodule: the matrix comes from OUR generator driven by the
+		// same feature vector (host/synthetic.cpp); `distribution` and `placement` are echoed, the generator has one of each
+		// (normal row lengths — log-normal when std > avg/2 — and random placement inside the band).
+		if (argc < 12)
+		{
+			fprintf(stderr, "usage (USE_ARTIFICIAL_MATRICES=1): %s nr_rows nr_cols avg_nnz_per_row std_nnz_per_row distribution placement "
+					"avg_bw skew avg_num_neighbours cross_row_similarity seed [matrix_name]\n", argv[0]);
+			return 1;
+		}
+		const long nr_rows = atol(argv[1]), nr_cols = atol(argv[2]);
+		snprintf(am_distribution, sizeof(am_distribution), "%s", argv[5]);
+		snprintf(am_placement, sizeof(am_placement), "%s", argv[6]);
+		am_seed = atol(argv[11]);
+		spmv_host_csr csr;
+		t = now();
+		if (spmv_host_gen_twin(nr_rows, nr_cols, atof(argv[3]), atof(argv[4]), atof(argv[7]), atof(argv[8]), atof(argv[9]), atof(argv[10]),
+				(unsigned long) am_seed, 0, &csr))
+		{
+			fprintf(stderr, "%s\n", spmv_host_last_error());
+			return 1;
+		}
+		printf("time generate artificial matrix: %lf\n", now() - t);
+		keep_symmetry = 0;
+		m = csr.m; n = csr.n; nnz = csr.nnz;
+		ia.assign(csr.row_ptr, csr.row_ptr + m + 1);
+		ja.assign(csr.col_idx, csr.col_idx + nnz);
+		a_ref.assign(csr.values, csr.values + nnz);
+		spmv_host_csr_free(&csr);
+		for (long i = 0; i < m; i++)
+			for (long j = ia[i]; j < ia[i + 1]; j++)
+				(ja[j] == i ? nnz_diag : nnz_non_diag)++;
+		spmv_host_csr_am_stats(ia.data(), ja.data(), m, n, am, am_range, sizeof(am_range));
+		if (argc > 12)
+			snprintf(matrix_name, sizeof(matrix_name), "%s_artificial", argv[12]);
+		else
+			snprintf(matrix_name, sizeof(matrix_name), "%ld_%ld_%ld_%g_%g_%g_%g", m, n, nnz, am[4], am[5], am[8], am[9]);      // bench.cpp:583-585
+	}
+	else if (!strcmp(argv[1], "--twin"))
 	{
 		if (argc < 3)
 		{
@@ -334,6 +384,21 @@ main(int argc, char ** argv)
 
 	char buf[10000];
 	long i = 0;
+	if (use_artificial && am_distribution[0])
+	{
+		// bench_spmv.cpp:532-559 (the accuracy check still runs and prints to stdout; this row carries no error columns)
+		i += snprintf(buf + i, sizeof(buf) - i, "synthetic,%s,%s,%ld,%lu,%lu,%lu", am_distribution, am_placement, am_seed, m, n, nnz);
+		i += snprintf(buf + i, sizeof(buf) - i, ",%lf,%lf,%s", am[0], am[1], am_range);
+		for (int k = 2; k < 15; k++)
+			i += snprintf(buf + i, sizeof(buf) - i, ",%lf", am[k]);
+		i += snprintf(buf + i, sizeof(buf) - i, ",%s,%lf,%lf,%lf,%lf", MF->format_name, time_total, gflops, 0.0, 0.0);
+		char scratch[2000];
+		check_accuracy(scratch, sizeof(scratch), ia.data(), ja.data(), a_ref.data(), m, x_ref.data(), y, false);
+		fprintf(stderr, "%s\n", buf);
+		free(x);
+		free(y);
+		return 0;
+	}
 	i += snprintf(buf + i, sizeof(buf) - i, "%s,%d,%lu,%lu,%lu,%lu", matrix_name, num_threads, m, n, nnz, symmetric);
 	i += snprintf(buf + i, sizeof(buf) - i, ",%lf,%lf,%lf,%lf,%lf", time_total, time_min, time_median, time_max, gflops);
 	i += snprintf(buf + i, sizeof(buf) - i, ",%lf,%lf,%lf", MF->csr_mem_footprint / (1024 * 1024), 0.0, 0.0);

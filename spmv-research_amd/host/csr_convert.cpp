@@ -112,4 +112,67 @@ csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, d
 	return 0;
 }
 
+// The statistics the reference's artificial-matrix mode prints beside every result (bench_spmv.cpp:489-563: the fields of the
+// generator's struct csr_matrix). The generator itself is an un-vendored submodule, so the definitions are taken from where the
+// tree still states them: per-row bandwidth b = col_max - col_min and scatter s = degree / b (0 when b = 0)
+// (lib/storage_formats/csr_util/csr_util_gen.c:437-449), density in percent and the CSR footprint in MiB with fp64 values and the
+// power-of-two memory class (benchmark_code/FPGA/csr_to_vitis_converter/v2/artificial_matrix_generation.py:130-132,243-256);
+// "scaled" = the same quantity with the bandwidth divided by the number of columns.
+//   out[0..14] = density, mem_footprint, avg_nnz_per_row, std_nnz_per_row, avg_bw, std_bw, avg_bw_scaled, std_bw_scaled, avg_sc, std_sc,
+//                avg_sc_scaled, std_sc_scaled, skew, avg_num_neighbours, cross_row_similarity;   mem_range = "[lo-hi]" (MiB)
+int
+csr_am_stats(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out, char * mem_range, long mem_range_n)
+{
+	double f[7];
+	csr_features(row_ptr, col_idx, m, n, f);
+	const long nnz = row_ptr[m];
+	double sb = 0, sbb = 0, ss = 0, sss = 0;
+	#pragma omp parallel for num_threads(spmv::host_threads()) reduction(+ : sb, sbb, ss, sss) schedule(static, 4096)
+	for (long i = 0; i < m; i++)
+	{
+		const long d = row_ptr[i + 1] - row_ptr[i];
+		if (d == 0)
+			continue;
+		const double b = (double) col_idx[row_ptr[i + 1] - 1] - col_idx[row_ptr[i]];
+		const double sc = b > 0 ? (double) d / b : 0;
+		sb += b;
+		sbb += b * b;
+		ss += sc;
+		sss += sc * sc;
+	}
+	const double mm = m > 0 ? (double) m : 1, nn = n > 0 ? (double) n : 1;
+	const double avg_bw = sb / mm, std_bw = sqrt(std::max(0.0, sbb / mm - avg_bw * avg_bw));
+	const double avg_sc = ss / mm, std_sc = sqrt(std::max(0.0, sss / mm - avg_sc * avg_sc));
+	const double footprint = ((64.0 + 32.0) * nnz + 32.0 * (m + 1)) / (8.0 * 1024 * 1024);
+	out[0] = (m > 0 && n > 0) ? (double) nnz / ((double) m * n) * 100.0 : 0;
+	out[1] = footprint;
+	out[2] = f[0];
+	out[3] = f[1];
+	out[4] = avg_bw;
+	out[5] = std_bw;
+	out[6] = avg_bw / nn;
+	out[7] = std_bw / nn;
+	out[8] = avg_sc;
+	out[9] = std_sc;
+	out[10] = avg_sc * nn;
+	out[11] = std_sc * nn;
+	out[12] = f[3];
+	out[13] = f[4];
+	out[14] = f[5];
+	if (mem_range && mem_range_n > 0)
+	{
+		long lo = 4, hi = 8;
+		while (hi < 4096 && footprint >= hi)
+		{
+			lo = hi;
+			hi *= 2;
+		}
+		if (footprint < 4 || footprint >= 4096)
+			snprintf(mem_range, mem_range_n, "[-]");
+		else
+			snprintf(mem_range, mem_range_n, "[%ld-%ld]", lo, hi);
+	}
+	return 0;
+}
+
 }  // namespace spmv_host

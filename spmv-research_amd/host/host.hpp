@@ -50,6 +50,7 @@ int permuted_block(const int32_t * rp, const int32_t * ci, const double * va, lo
 int halo_lists(const int32_t * rp, const int32_t * ci, long m, const int32_t * owner, long parts, long rank,
 		long * send_offsets, int32_t ** send_list, long * recv_offsets, int32_t ** recv_list);
 int csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out7);
+int csr_am_stats(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out15, char * mem_range, long mem_range_n);
 
 // counter-based generator: independent stream per (seed, row) so the generators are parallel AND deterministic
 struct Rng {

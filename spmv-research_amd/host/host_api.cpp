@@ -247,6 +247,12 @@ spmv_host_gen_named(const char * name, double scale, spmv_host_csr * out)
 }
 
 int
+spmv_host_csr_am_stats(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out15, char * mem_range, long mem_range_n)
+{
+	return csr_am_stats(row_ptr, col_idx, m, n, out15, mem_range, mem_range_n);
+}
+
+int
 spmv_host_csr_features(const int32_t * row_ptr, const int32_t * col_idx, long m, long n, double * out7)
 {
 	return csr_features(row_ptr, col_idx, m, n, out7);

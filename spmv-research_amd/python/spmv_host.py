@@ -15,7 +15,7 @@ SYMBOLS = [
     "spmv_host_gen_kkt_row_ptr", "spmv_host_gen_kkt_block", "spmv_host_remap_columns", "spmv_host_column_ranges",
     "spmv_host_bfs_order", "spmv_host_owners_from_order", "spmv_host_partition_volume", "spmv_host_partition_layout",
     "spmv_host_permuted_block", "spmv_host_halo_lists", "spmv_host_gen_kkt_rows", "spmv_host_jitter_columns",
-    "spmv_host_kkt_bfs_owner", "spmv_host_kkt_partition_volume",
+    "spmv_host_kkt_bfs_owner", "spmv_host_kkt_partition_volume", "spmv_host_csr_am_stats",
 ]
 
 
@@ -283,3 +283,19 @@ def csr_features(row_ptr, col_idx, m, n):
     out = np.zeros(7)
     _check(lib().spmv_host_csr_features(_p(row_ptr), _p(col_idx), C.c_long(m), C.c_long(n), _p(out)))
     return dict(zip(FEATURES, out.tolist()))
+
+
+AM_STATS = ("density", "mem_footprint", "avg_nnz_per_row", "std_nnz_per_row", "avg_bw", "std_bw", "avg_bw_scaled", "std_bw_scaled",
+            "avg_sc", "std_sc", "avg_sc_scaled", "std_sc_scaled", "skew", "avg_num_neighbours", "cross_row_similarity")
+
+
+def csr_am_stats(row_ptr, col_idx, m, n):
+    """The matrix statistics of the reference's artificial-matrix CSV row (bench_spmv.cpp:489-563)."""
+    row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+    col_idx = np.ascontiguousarray(col_idx, np.int32)
+    out = np.zeros(15)
+    buf = C.create_string_buffer(32)
+    _check(lib().spmv_host_csr_am_stats(_p(row_ptr), _p(col_idx), C.c_long(m), C.c_long(n), _p(out), buf, C.c_long(32)))
+    d = dict(zip(AM_STATS, out.tolist()))
+    d["mem_range"] = buf.value.decode()
+    return d

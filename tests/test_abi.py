@@ -86,6 +86,22 @@ def test_driver_prints_the_reference_csv_header():
     assert r.stderr.strip() == want
 
 
+def test_driver_prints_the_reference_artificial_matrix_csv_header():
+    """USE_ARTIFICIAL_MATRICES=1 (bench.cpp:497, config.sh conf_vars): no argument -> the synthetic-dataset label line of
+    bench_spmv.cpp:493-522."""
+    import subprocess
+    exe = os.path.join(ROOT, "spmv-research_amd", "bin", "spmv_mi355x_bench")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60, env=dict(os.environ, USE_ARTIFICIAL_MATRICES="1"))
+    assert r.returncode == 0
+    want = ("matrix_name,distribution,placement,seed,nr_rows,nr_cols,nr_nzeros,density,mem_footprint,mem_range,avg_nnz_per_row,"
+            "std_nnz_per_row,avg_bw,std_bw,avg_bw_scaled,std_bw_scaled,avg_sc,std_sc,avg_sc_scaled,std_sc_scaled,skew,"
+            "avg_num_neighbours,cross_row_similarity,format_name,time,gflops,W_avg,J_estimated")
+    assert r.stderr.strip() == want
+    # too few generator parameters: usage, not a crash (the reference reads argv unchecked)
+    r = subprocess.run([exe, "100", "100"], capture_output=True, text=True, timeout=60, env=dict(os.environ, USE_ARTIFICIAL_MATRICES="1"))
+    assert r.returncode == 1 and "avg_nnz_per_row" in r.stderr
+
+
 def test_driver_prints_the_reference_solver_csv_header():
     import subprocess
     exe = os.path.join(ROOT, "spmv-research_amd", "bin", "spmv_mi355x_bench")

@@ -110,3 +110,19 @@ def test_adapter_honours_ngpus(tmp_path):
     row = [l for l in r.stderr.splitlines() if "MI355X_PART3_" in l]
     assert len(row) == 1, r.stderr[-2000:]
     assert "Test failed" not in r.stdout + r.stderr
+
+
+def test_driver_artificial_matrix_mode(tmp_path):
+    """USE_ARTIFICIAL_MATRICES=1: the generator's feature vector on the command line (bench.cpp:569-579), the synthetic-dataset CSV row
+    (bench_spmv.cpp:532-559) on stderr."""
+    exe = os.path.join(ROOT, "spmv-research_amd", "bin", "spmv_mi355x_bench")
+    env = dict(os.environ, USE_ARTIFICIAL_MATRICES="1", SPMV_MI355X_FORMAT="csr_vector", GPU_KERNEL="0", OMP_NUM_THREADS="4")
+    args = "20000 20000 12.5 3.0 normal random 0.05 2.0 1.2 0.6 14 mytest".split()
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    row = [l for l in r.stderr.splitlines() if l.startswith("synthetic,")]
+    assert len(row) == 1, r.stderr[-2000:]
+    f = row[0].split(",")
+    assert len(f) == 28 and f[1:4] == ["normal", "random", "14"] and f[4:6] == ["20000", "20000"] and f[23].startswith("MI355X_CSR_VECTOR")
+    assert abs(float(f[10]) - 12.5) < 0.2 and float(f[25]) > 0                      # avg_nnz_per_row as asked, gflops measured
+    assert "Test failed" not in r.stdout + r.stderr and "time generate artificial matrix" in r.stdout

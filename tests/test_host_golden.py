@@ -298,3 +298,23 @@ def test_reader_keeps_the_file_entries_first_for_keep_symmetry_callers():
         assert np.array_equal(rp, z["sym_row_ptr"]) and np.array_equal(ci, z["sym_col_idx"]) and np.array_equal(a, z["sym_values"])
         n_checked += 1
     assert n_checked >= 5
+
+
+def test_artificial_matrix_statistics():
+    """The statistics of the artificial-matrix CSV row (bench_spmv.cpp:532-554) on a matrix small enough to do by hand, with the
+    definitions the tree still states (csr_util_gen.c:437-449: bandwidth = col_max - col_min, scatter = degree / bandwidth)."""
+    import spmv_host as H
+    rp = np.array([0, 3, 3, 5, 6], np.int32)
+    ci = np.array([0, 2, 6, 1, 2, 7], np.int32)           # rows: {0,2,6}, {}, {1,2}, {7}
+    s = H.csr_am_stats(rp, ci, 4, 8)
+    bw = np.array([6.0, 0.0, 1.0, 0.0])
+    sc = np.array([3 / 6, 0.0, 2 / 1, 0.0])
+    assert s["density"] == pytest.approx(6 / 32 * 100) and s["mem_footprint"] == pytest.approx((96 * 6 + 32 * 5) / (8 * 1024 * 1024))
+    assert s["avg_nnz_per_row"] == pytest.approx(1.5) and s["std_nnz_per_row"] == pytest.approx(np.std([3, 0, 2, 1]))
+    assert s["avg_bw"] == pytest.approx(bw.mean()) and s["std_bw"] == pytest.approx(bw.std())
+    assert s["avg_bw_scaled"] == pytest.approx(bw.mean() / 8) and s["avg_sc"] == pytest.approx(sc.mean()) and s["std_sc"] == pytest.approx(sc.std())
+    assert s["skew"] == pytest.approx((3 - 1.5) / 1.5) and s["mem_range"] == "[-]"            # far below the 4 MiB class
+    A = H.gen_named("cant", 1.0)
+    t = H.csr_am_stats(A["row_ptr"], A["col_idx"], A["m"], A["n"])
+    f = H.csr_features(A["row_ptr"], A["col_idx"], A["m"], A["n"])
+    assert t["mem_range"] == "[32-64]" and t["avg_bw_scaled"] == pytest.approx(f["avg_bw_scaled"]) and t["skew"] == pytest.approx(f["skew"])
