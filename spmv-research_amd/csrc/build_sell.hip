@@ -458,9 +458,9 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 		// waves per slice: enough wavefronts to occupy 256 CUs several times over
 		const long slices = (lm + 63) / 64;
 		int S = o.sell_split ? o.sell_split : (slices >= 16384 ? 1 : slices >= 8192 ? 2 : 4);
-		if (S != 1 && S != 2 && S != 4)
+		if (S != 1 && S != 2 && S != 4 && !(S == 8 && o.sell_window == 1))
 		{
-			set_error("sell_split must be 1, 2 or 4 (got %d)", S);
+			set_error("sell_split must be 1, 2 or 4 (8 with sell_window = 1) (got %d)", S);
 			return 1;
 		}
 		A->sell_split = A->sell_delta ? S : 1;
@@ -499,6 +499,12 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 			{
 				A->sell_window = true;
 				A->sell_delta = false;
+				// Matrix streams of this kernel are read once per launch and x lives in LDS: when an XCD's share of the stream
+				// exceeds its 4 MiB L2 (stream > 32 MiB), letting it allocate there only evicts the window sources and descriptors —
+				// nontemporal loads: cant twin fp64 (41 MB) 9.4 -> 8.5 us; below that size the stream itself stays L2-resident from
+				// launch to launch and nt would throw that away (cant twin fp32, 21 MB: 3.9 -> 5.6 us)
+				if (o.nontemporal == 0)
+					A->cfg.nt = (double) A->sell_nnz_ext * (A->vbytes + 2) > 32.0 * 1024 * 1024 ? 1 : 0;
 				A->sell_sigma = 64L * NS;
 				if (S > 1)
 					snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELLW_64_%d_w%d_%s", 64 * NS, S, pf);

@@ -193,8 +193,9 @@ sell_window_dispatch(int S, int threads, const int * grp, const int64_t * sdesc,
 		case 1: return sell_window_launch_s<T, 1>(threads, grp, sdesc, idx, val, row_of_sorted, x, y, m, lds_window_bytes, cfg, stream, grid_out);
 		case 2: return sell_window_launch_s<T, 2>(threads, grp, sdesc, idx, val, row_of_sorted, x, y, m, lds_window_bytes, cfg, stream, grid_out);
 		case 4: return sell_window_launch_s<T, 4>(threads, grp, sdesc, idx, val, row_of_sorted, x, y, m, lds_window_bytes, cfg, stream, grid_out);
+		case 8: return sell_window_launch_s<T, 8>(threads, grp, sdesc, idx, val, row_of_sorted, x, y, m, lds_window_bytes, cfg, stream, grid_out);
 	}
-	set_error("sell window: waves per slice must be 1, 2 or 4 (got %d)", S);
+	set_error("sell window: waves per slice must be 1, 2, 4 or 8 (got %d)", S);
 	return 1;
 }
 
