@@ -417,10 +417,12 @@ def run(args, B):
     c.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # a gloo rehearsal may put several ranks on one GPU
     torch.cuda.set_device(local_rank)
-    if args.backend == "nccl":
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(backend=args.backend)
+    with B.QuietStdout():                      # the gloo transport announces its connections on C stdout; ours carries ONE JSON line
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
+            dist.barrier()
     dev = torch.device("cuda") if args.backend == "nccl" else torch.device("cpu")
     workload = args.workload
     c.fmt = args.format or B.DEFAULT_FORMAT.get(workload, "csr_vector")
