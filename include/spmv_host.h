@@ -85,6 +85,10 @@ int  spmv_host_gen_kkt_row_ptr(long N, int32_t * row_ptr /* [m+1] or NULL */, lo
 int  spmv_host_gen_kkt_block(long N, unsigned long seed, long row_begin, long row_end, spmv_host_csr * out);
 /* An arbitrary ascending list of rows of the same matrix as a local CSR (a rank's rows under a graph partition). */
 int  spmv_host_gen_kkt_rows(long N, unsigned long seed, const int32_t * rows, long count, spmv_host_csr * out);
+/* The same into CALLER-allocated arrays — rows[count] (or the contiguous rows row_begin.. when rows is NULL), row_ptr[count+1],
+ * col_idx[capacity], values[capacity] or NULL for the structure alone: no second copy of a rank's block is ever made. */
+int  spmv_host_gen_kkt_rows_into(long N, unsigned long seed, const int32_t * rows, long row_begin, long count, int32_t * row_ptr,
+		int32_t * col_idx, double * values, long capacity);
 /* In place: in a fraction `frac` of the rows every off-diagonal column moves by a random offset in [-span, span] (rows stay
  * sorted and duplicate-free). Breaks the translation invariance of a generated matrix: bench.py --jitter measures how much
  * of the compressed-index SELL format's advantage rests on it. */

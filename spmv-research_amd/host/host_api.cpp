@@ -155,6 +155,13 @@ spmv_host_gen_kkt_rows(long N, unsigned long seed, const int32_t * rows, long co
 }
 
 int
+spmv_host_gen_kkt_rows_into(long N, unsigned long seed, const int32_t * rows, long row_begin, long count, int32_t * row_ptr, int32_t * col_idx,
+		double * values, long capacity)
+{
+	return gen_kkt_rows_into(N, seed, rows, row_begin, count, row_ptr, col_idx, values, capacity);
+}
+
+int
 spmv_host_jitter_columns(long m, long n, const int32_t * row_ptr, int32_t * col_idx, double * values, double frac, long span, unsigned long seed)
 {
 	return jitter_columns(m, n, row_ptr, col_idx, values, frac, span, seed);

@@ -299,6 +299,48 @@ gen_kkt_some(long N, unsigned long seed, const int32_t * rows, long r0, long lm,
 	return 0;
 }
 
+// the same rows written into CALLER-allocated arrays (row_ptr[count+1], col_idx[nnz], values[nnz] or NULL for the structure alone):
+// a rank of a multi-GPU run knows its rows' lengths from the global row_ptr and never needs a second copy of its block
+int
+gen_kkt_rows_into(long N, unsigned long seed, const int32_t * rows, long r0, long count, int32_t * row_ptr, int32_t * col_idx, double * values,
+		long capacity)
+{
+	Grid G;
+	if (make_grid(N, G))
+		return 1;
+	const long m = G.n1 + G.n2;
+	auto row_of = [&](long li) { return rows ? (long) rows[li] : r0 + li; };
+	long acc = 0;
+	row_ptr[0] = 0;
+	for (long i = 0; i < count; i++)
+	{
+		const long r = row_of(i);
+		if (r < 0 || r >= m)
+		{
+			set_error("KKT row list: entry %ld is outside [0,%ld)", i, m);
+			return 1;
+		}
+		acc += kkt_row_len(G, r);
+		if (acc >= 0x7fffffffL || acc > capacity)
+		{
+			set_error("KKT rows: %ld non-zeros exceed the caller's arrays (%ld) or the int32 index range", acc, capacity);
+			return 1;
+		}
+		row_ptr[i + 1] = (int32_t) acc;
+	}
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 8192)
+	for (long li = 0; li < count; li++)
+	{
+		const long i = row_of(li);
+		int32_t * ci = col_idx + row_ptr[li];
+		const int k = kkt_row_cols(G, i, ci);
+		if (values)
+			for (int q = 0; q < k; q++)
+				values[row_ptr[li] + q] = sym_value(seed, i, ci[q]);
+	}
+	return 0;
+}
+
 int
 gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out)
 {

@@ -43,15 +43,17 @@ class Source:
 
     def block(self, r0, r1):
         if self.kkt:
-            return self.H.gen_kkt_block(self.N, r0, r1)
+            return self.H.gen_kkt_rows_into(self.N, int(self.row_ptr[r1]) - int(self.row_ptr[r0]), r0=r0, count=r1 - r0)
         A = self.A
         s, e = int(A["row_ptr"][r0]), int(A["row_ptr"][r1])
         return dict(m=r1 - r0, n=self.n, nnz=e - s, row_ptr=(A["row_ptr"][r0:r1 + 1] - s).astype(np.int32),
                     col_idx=np.ascontiguousarray(A["col_idx"][s:e]).copy(), values=np.ascontiguousarray(A["values"][s:e]).copy())
 
-    def rows(self, rows):
+    def rows(self, rows, values=True):
+        """An ascending list of rows as a CSR with original column numbers; values=False: the structure alone."""
         if self.kkt:
-            return self.H.gen_kkt_rows(self.N, rows)
+            nnz = int((self.row_ptr[np.asarray(rows, np.int64) + 1].astype(np.int64) - self.row_ptr[np.asarray(rows, np.int64)]).sum())
+            return self.H.gen_kkt_rows_into(self.N, nnz, rows=rows, values=values)
         A = self.A
         ident = np.arange(self.n, dtype=np.int32)
         return self.H.permuted_block(A["row_ptr"], A["col_idx"], A["values"], np.ascontiguousarray(rows, np.int32), ident, 0, len(rows))
@@ -266,13 +268,22 @@ class GraphVariant:
         n = c.src.n
         t0 = time.time()
         mine = np.flatnonzero(owner == c.rank).astype(np.int32)           # the rank's rows, ascending original order
-        blk = c.src.rows(mine)
-        order, split, interior, boundary = D.split_interior_boundary(blk, owner, c.rank)
-        self.rows = mine[order]
+        # pass 1 on the STRUCTURE alone: which rows read a peer's x (boundary), which x entries arrive from whom
+        st = c.src.rows(mine, values=False)
+        lens = np.diff(st["row_ptr"].astype(np.int64))
+        remote = owner[st["col_idx"]] != c.rank
+        per_row = np.zeros(len(mine), np.int64)
+        nz = np.flatnonzero(lens > 0)
+        if len(nz):
+            per_row[nz] = np.add.reduceat(remote.astype(np.int64), st["row_ptr"][:-1][nz].astype(np.int64))
+        recv = D.recv_lists_from_block(st, owner, c.rank, c.world)
+        del st, remote
+        is_b = per_row > 0
+        rows_int, rows_bnd = mine[~is_b], mine[is_b]                      # both ascending; every row whole
+        split = int(len(rows_int))
+        self.rows = np.concatenate([rows_int, rows_bnd])
         self.split, self.lm = split, len(mine)
-        recv = D.recv_lists_from_block(blk, owner, c.rank, c.world)
-        self.samples = _take_samples(interior, 0, None, 1000) + _take_samples(boundary, split, None, 1000, seed=2)
-        del blk                                                           # interior + boundary hold every row once
+        self.samples = []
         self.t_gen = time.time() - t0
         dev = torch.device("cuda") if c.args.backend == "nccl" else torch.device("cpu")
         send = D.exchange_send_lists(dist, torch, recv, c.rank, c.world, dev)
@@ -307,17 +318,18 @@ class GraphVariant:
             raise SystemExit("the packed halo exchange did not validate on every rank")
         del mine_dev
         t0 = time.time()
-        if c.args.overlap:
-            # (handle, first row of y it writes, phase: 0 = while the halo is in flight, 1 = after it has arrived)
-            self.launches = [(E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n, c.fmt, c.np_dtype, **c.opts), first, phase)
-                             for b, first, phase in ((interior, 0, 0), (boundary, split, 1)) if b["m"] > 0]
-        else:
-            del interior, boundary
-            whole = c.src.rows(self.rows)
-            self.launches = [(E.Matrix(whole["row_ptr"], whole["col_idx"], whole["values"], whole["m"], n, c.fmt, c.np_dtype, **c.opts), 0, 1)]
-            del whole
+        self.launches = []
+        # (handle, first row of y it writes, phase: 0 = while the halo is in flight, 1 = after it has arrived); a block's host copy
+        # lives only while its handle is being built
+        parts = ((rows_int, 0, 0), (rows_bnd, split, 1)) if c.args.overlap else ((self.rows, 0, 1),)
+        for k, (rws, first, phase) in enumerate(parts):
+            if len(rws) == 0:
+                continue
+            b = c.src.rows(rws)
+            self.samples += _take_samples(b, first, None, 1000, seed=1 + k)
+            self.launches.append((E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n, c.fmt, c.np_dtype, **c.opts), first, phase))
+            del b
         self.mats = [l[0] for l in self.launches]
-        interior = boundary = None
         self.t_conv = time.time() - t0
         self.y = torch.full((self.lm + 64,), 1.0, dtype=c.t_dtype, device="cuda")
         self.exchange_info = {"chosen": "packed halo " + self.packed.mode, "recv_x_entries": self.packed.recv_elems,

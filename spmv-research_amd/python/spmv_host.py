@@ -15,7 +15,7 @@ SYMBOLS = [
     "spmv_host_gen_kkt_row_ptr", "spmv_host_gen_kkt_block", "spmv_host_remap_columns", "spmv_host_column_ranges",
     "spmv_host_bfs_order", "spmv_host_owners_from_order", "spmv_host_partition_volume", "spmv_host_partition_layout",
     "spmv_host_permuted_block", "spmv_host_halo_lists", "spmv_host_gen_kkt_rows", "spmv_host_jitter_columns",
-    "spmv_host_kkt_bfs_owner", "spmv_host_kkt_partition_volume", "spmv_host_csr_am_stats",
+    "spmv_host_kkt_bfs_owner", "spmv_host_kkt_partition_volume", "spmv_host_csr_am_stats", "spmv_host_gen_kkt_rows_into",
 ]
 
 
@@ -169,6 +169,21 @@ def gen_kkt_rows(N, rows, seed=14):
     csr = _Csr()
     _check(lib().spmv_host_gen_kkt_rows(C.c_long(N), C.c_ulong(seed), _p(rows), C.c_long(len(rows)), C.byref(csr)))
     return _take_csr(csr)
+
+
+def gen_kkt_rows_into(N, nnz, rows=None, r0=0, count=None, values=True, seed=14):
+    """Rows of the KKT matrix written straight into numpy arrays of the right size (nnz = their total length, known from the global
+    row_ptr): the CSR dict without the second copy gen_kkt_rows makes. values=False: structure only (values is None)."""
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, np.int32)
+        count = len(rows)
+    rp = np.zeros(count + 1, np.int32)
+    ci = np.empty(max(nnz, 1), np.int32)
+    va = np.empty(max(nnz, 1), np.float64) if values else None
+    _check(lib().spmv_host_gen_kkt_rows_into(C.c_long(N), C.c_ulong(seed), None if rows is None else _p(rows), C.c_long(r0), C.c_long(count),
+                                             _p(rp), _p(ci), None if va is None else _p(va), C.c_long(nnz)))
+    assert int(rp[count]) == nnz
+    return dict(m=count, n=kkt_size(N), nnz=nnz, row_ptr=rp, col_idx=ci[:nnz], values=None if va is None else va[:nnz])
 
 
 def jitter_columns(A, frac, span=3, seed=14):
