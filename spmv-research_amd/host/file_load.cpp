@@ -202,7 +202,7 @@ untar_first(const char * path, FileBuf & io)
 		const size_t sz = (size_t) strtoull(szbuf, NULL, 8);
 		const char type = p[156];
 		const char * body = p + 512;
-		if (body + sz > e)
+		if (sz > (size_t) (e - body))              // compared as sizes: `body + sz` would wrap for a crafted octal size
 			break;
 		if ((type == '0' || type == 0) && sz > 0)
 		{

@@ -476,6 +476,22 @@ def test_symmetric_input_matches_reference_csr_sym(eng, oracle, case):
                 G.close()
 
 
+def test_create_rejects_non_monotone_row_ptr_before_sizing_anything(eng):
+    """A row_ptr whose lengths go +10 then -10 used to size the filtered copy from the final prefix sum (0) and overflow it while
+    writing at the per-row offsets, before the monotonicity check ran (advisor finding, round 1): now refused up front, on every
+    path (plain, row block, column filter)."""
+    rp = np.array([0, 10, 0], np.int32)
+    ci = np.zeros(10, np.int32)
+    a = np.ones(10)
+    for opts in ({}, {"row_begin": 0, "row_end": 2, "col_begin": 0, "col_end": 1, "col_filter_mode": 1},
+                 {"col_begin": 0, "col_end": 1, "col_filter_mode": 2}):
+        with pytest.raises(eng.SpmvError, match="monotone|does not match"):
+            eng.Matrix(rp, ci, a, 2, 4, "csr_vector", **opts)
+    rp2 = np.array([5, 15, 10, 15], np.int32)                       # a row block of a global CSR, not monotone inside
+    with pytest.raises(eng.SpmvError, match="monotone"):
+        eng.Matrix(rp2, np.zeros(10, np.int32), a, 3, 4, "csr_vector")
+
+
 def test_symmetric_input_rejects_bad_input(eng):
     rp = np.array([0, 1, 3], np.int32)
     ci = np.array([0, 0, 1], np.int32)

@@ -268,6 +268,30 @@ def test_reader_accepts_compressed_and_archived_inputs(case, tmp_path):
     same(tmp_path / "e.mtx.zst")
 
 
+def test_tar_member_with_an_impossible_size_is_refused(tmp_path):
+    """A tar header whose octal size field is astronomically large (a crafted or torn archive) must be an error, not a pointer
+    that wraps past the end of the buffer (advisor finding, round 1)."""
+    import io
+    import tarfile
+    import spmv_host as H
+    from conftest import GOLDEN
+    text = open(os.path.join(GOLDEN, "general_real.mtx"), "rb").read()
+    bio = io.BytesIO()
+    with tarfile.open(fileobj=bio, mode="w", format=tarfile.USTAR_FORMAT) as tf:
+        ti = tarfile.TarInfo("m.mtx")
+        ti.size = len(text)
+        tf.addfile(ti, io.BytesIO(text))
+    raw = bytearray(bio.getvalue())
+    raw[124:136] = b"77777777777\0"                  # size = 8 GiB - 1 for a member of a few KB
+    (tmp_path / "bad.tar").write_bytes(bytes(raw))
+    with pytest.raises(H.HostError):
+        H.mtx_read(str(tmp_path / "bad.tar"))
+    raw[124:136] = b"7" * 12                         # no terminator: strtoull reads 12 octal digits (64 GiB)
+    (tmp_path / "bad2.tar").write_bytes(bytes(raw))
+    with pytest.raises(H.HostError):
+        H.mtx_read(str(tmp_path / "bad2.tar"))
+
+
 def test_reader_reports_corrupt_compressed_input(tmp_path):
     import gzip
     import spmv_host as H
