@@ -14,7 +14,7 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 {
 	const long lm = A->m, lnnz = A->nnz, n = A->n;
 	const char * pf = A->f32 ? "f" : "d";
-	const int WGS = coo_blocked_wgs_per_range(), CH = coo_blocked_chunk_rows(), KMAX = coo_blocked_max_long_rows();
+	const int WGS = coo_blocked_wgs_per_range(), RND = coo_blocked_chunk_rows(), KMAX = coo_blocked_max_long_rows();
 	const long cap = coo_blocked_rows_cap(A->f32);                 // chunk rows per workgroup (KMAX more slots are set aside for split rows)
 	const long range_cap = cap * WGS;                              // rows per range
 	const long P = std::max<long>(1, (lm + NUM_XCD * range_cap - 1) / (NUM_XCD * range_cap));
@@ -45,7 +45,7 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 			const long tgt = (long) ((double) lnnz * r / NR);
 			row = std::lower_bound(rp, rp + lm + 1, (int) std::min<long>(tgt, 0x7fffffffL)) - rp;
 		}
-		row = std::min<long>(lm, (row + CH / 2) / CH * CH);
+		row = std::min<long>(lm, (row + RND / 2) / RND * RND);
 		range_row[r] = (int) std::max<long>(row, range_row[r - 1]);
 	}
 	range_row[NR] = (int) lm;
@@ -53,7 +53,7 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 		fits = fits && range_row[r + 1] - range_row[r] <= range_cap;
 	if (!fits)
 	{
-		const long per = ((lm + NR - 1) / NR + CH - 1) / CH * CH;
+		const long per = ((lm + NR - 1) / NR + RND - 1) / RND * RND;
 		for (long r = 0; r <= NR; r++)
 			range_row[r] = (int) std::min<long>(lm, r * per);
 	}
@@ -86,6 +86,22 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 		a = rp[row] + len * j / WGS;
 		b = rp[row] + len * (j + 1) / WGS;
 	};
+	// ---- how a range's rows are dealt to its 32 workgroups: chunks of CH rows, round-robin. CH = 16 (default): every workgroup sees
+	// the whole range's column structure, entries per block are even. SPMV_MI355X_COOB_CHUNK=0: ONE contiguous chunk per workgroup
+	// (fewer distinct x lines per workgroup on banded graphs, uneven block fill at the range's ends).
+	long CH = RND;
+	if (const char * e = getenv("SPMV_MI355X_COOB_CHUNK"))
+	{
+		if (atol(e) == 0)
+		{
+			long widest = 0;
+			for (long r = 0; r < NR; r++)
+				widest = std::max<long>(widest, range_row[r + 1] - range_row[r]);
+			CH = std::max<long>(RND, ((widest + WGS - 1) / WGS + RND - 1) / RND * RND);
+		}
+		else if (atol(e) >= RND && atol(e) % RND == 0 && atol(e) <= cap)
+			CH = atol(e);
+	}
 	// ---- column blocks, per range (the 32 workgroups of a range walk the same blocks in step): every block spans at most 65 536
 	// columns (16-bit offsets). col_blocks > 0: uniform blocks of ceil(n / col_blocks) columns. col_blocks = -1: EQUI-DEPTH blocks —
 	// as many columns as hold one full batch of entries per workgroup (85 % of it on average: the deal is statistical), so that
@@ -302,7 +318,7 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 	}
 	A->coob_ranges = (int) NR;
 	A->coob_blocks = (int) B;
-	A->coob_block_cols = 0;
+	A->coob_block_cols = (int) CH;                // rows per chunk of the deal (the field's second life)
 	A->coob_num_long = (int) NL;
 	A->coob_lds = (int) (((long) std::max(max_rows, 1) * 8 + 15) / 16 * 16);      // fp64 slots for both precisions
 	A->cfg.map = xcd_map_uniform(1, 0);

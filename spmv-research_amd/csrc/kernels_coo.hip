@@ -288,7 +288,7 @@ __global__ __launch_bounds__(COOB_THREADS) void
 coo_blocked_kernel(const int * __restrict__ wg_rows, const int * __restrict__ range_row, const int * __restrict__ seg_blk,
 		const int * __restrict__ range_blk, const int * __restrict__ range_long, const unsigned * __restrict__ ent,
 		const T * __restrict__ val, const T * __restrict__ x, T * __restrict__ y, T * __restrict__ carry,
-		int ranges_per_xcd, int max_blocks, int sync_every, T unit, int beta)
+		int ranges_per_xcd, int max_blocks, int chunk_rows, int sync_every, T unit, int beta)
 {
 	extern __shared__ __align__(16) unsigned char coob_smem[];
 	double * ys = reinterpret_cast<double *>(coob_smem);
@@ -341,7 +341,7 @@ coo_blocked_kernel(const int * __restrict__ wg_rows, const int * __restrict__ ra
 	const int nnorm = nloc - nlong;
 	for (int l = tid; l < nnorm; l += COOB_THREADS)
 	{
-		const int row = r0 + ((l / COOB_CHUNK) * COOB_WGS + j) * COOB_CHUNK + l % COOB_CHUNK;
+		const int row = r0 + ((l / chunk_rows) * COOB_WGS + j) * chunk_rows + l % chunk_rows;
 		if (row < r1)
 			y[row] = (T) (beta ? (double) y[row] + ys[l] : ys[l]);
 	}
@@ -411,10 +411,10 @@ coo_blocked_launch(const int * wg_rows, const int * range_row, const int * seg_b
 	static const int sync_every = [] { const char * e = getenv("SPMV_MI355X_COOB_SYNC"); return e ? atoi(e) : 1; }();
 	if (cfg.unit)
 		hipLaunchKernelGGL((coo_blocked_kernel<T, true>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, wg_rows, range_row, seg_blk, range_blk,
-				range_long, ent, (const T *) nullptr, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, sync_every, (T) cfg.unit_value, cfg.beta);
+				range_long, ent, (const T *) nullptr, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, block_cols, sync_every, (T) cfg.unit_value, cfg.beta);
 	else
 		hipLaunchKernelGGL((coo_blocked_kernel<T, false>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, wg_rows, range_row, seg_blk, range_blk,
-				range_long, ent, (const T *) val, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, sync_every, (T) 0, cfg.beta);
+				range_long, ent, (const T *) val, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, block_cols, sync_every, (T) 0, cfg.beta);
 	HIP_TRY(hipGetLastError());
 	if (num_long > 0)
 	{

@@ -248,6 +248,87 @@ sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * 
 	}
 }
 
+// Modes 1 and 2 put a dependent load in front of every gather (deltas -> column -> x): their index words are fetched one pair of
+// groups AHEAD, so that a trip costs one exposed round trip (the gathers) like the index-free modes, not two.
+template <int MODE>
+struct SellDeltaIdx {
+	sell_int4 base;
+	sell_uint2 d;                                  // MODE 1 uses d.x only
+};
+
+template <int MODE, bool NT>
+__device__ __forceinline__ void
+sell_delta_load_idx(SellDeltaIdx<MODE> & q, const unsigned char * __restrict__ gp /* uniform */, int lane)
+{
+	q.base = *reinterpret_cast<const sell_int4 *>(gp);
+	if constexpr (MODE == 1)
+		q.d.x = ld_stream<NT>(reinterpret_cast<const unsigned *>(gp + 16) + lane);
+	else
+		q.d = ld_stream<NT>(reinterpret_cast<const sell_uint2 *>(gp + 16) + lane);
+}
+
+template <int MODE>
+__device__ __forceinline__ void
+sell_delta_cols(const SellDeltaIdx<MODE> & q, int (&c)[4])
+{
+	if constexpr (MODE == 1)
+	{
+		c[0] = q.base.x + (int) (q.d.x & 255u);
+		c[1] = q.base.y + (int) ((q.d.x >> 8) & 255u);
+		c[2] = q.base.z + (int) ((q.d.x >> 16) & 255u);
+		c[3] = q.base.w + (int) (q.d.x >> 24);
+	}
+	else
+	{
+		c[0] = q.base.x + (int) (q.d.x & 0xffffu);
+		c[1] = q.base.y + (int) (q.d.x >> 16);
+		c[2] = q.base.z + (int) (q.d.y & 0xffffu);
+		c[3] = q.base.w + (int) (q.d.y >> 16);
+	}
+}
+
+// the full 4-step groups number g0, g0+gs, ... (n of them) of a slice in mode 1 / 2, two groups per trip, index words one trip ahead
+template <typename T, int MODE, bool NT>
+__device__ __forceinline__ void
+sell_delta_piped(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int lane, const T * __restrict__ x, T & s, int g0, int gs, int n)
+{
+	constexpr int GB = MODE == 1 ? 272 : 528;
+	if (n <= 0)
+		return;
+	auto gidx = [&](int k) { return g0 + (k < n ? k : n - 1) * gs; };       // past the end: the last group again (loaded, not used)
+	SellDeltaIdx<MODE> a, b, na, nb;
+	sell_delta_load_idx<MODE, NT>(a, ip + (size_t) gidx(0) * GB, lane);
+	sell_delta_load_idx<MODE, NT>(b, ip + (size_t) gidx(1) * GB, lane);
+	for (int k = 0; k < n; k += 2)
+	{
+		const int ga = gidx(k), gb = gidx(k + 1);
+		sell_delta_load_idx<MODE, NT>(na, ip + (size_t) gidx(k + 2) * GB, lane);
+		sell_delta_load_idx<MODE, NT>(nb, ip + (size_t) gidx(k + 3) * GB, lane);
+		const T * va = vp + (size_t) ga * 4 * WAVE;
+		const T * vb = vp + (size_t) gb * 4 * WAVE;
+		const T a0 = ld_stream<NT>(va), a1 = ld_stream<NT>(va + WAVE), a2 = ld_stream<NT>(va + 2 * WAVE), a3 = ld_stream<NT>(va + 3 * WAVE);
+		const T b0 = ld_stream<NT>(vb), b1 = ld_stream<NT>(vb + WAVE), b2 = ld_stream<NT>(vb + 2 * WAVE), b3 = ld_stream<NT>(vb + 3 * WAVE);
+		int ca[4], cb[4];
+		sell_delta_cols<MODE>(a, ca);
+		sell_delta_cols<MODE>(b, cb);
+		const T x0 = x[ca[0]], x1 = x[ca[1]], x2 = x[ca[2]], x3 = x[ca[3]];
+		const T z0 = x[cb[0]], z1 = x[cb[1]], z2 = x[cb[2]], z3 = x[cb[3]];
+		s = fma_t<T>(a0, x0, s);
+		s = fma_t<T>(a1, x1, s);
+		s = fma_t<T>(a2, x2, s);
+		s = fma_t<T>(a3, x3, s);
+		if (k + 1 < n)                               // wave-uniform: an odd count ends on a single group
+		{
+			s = fma_t<T>(b0, z0, s);
+			s = fma_t<T>(b1, z1, s);
+			s = fma_t<T>(b2, z2, s);
+			s = fma_t<T>(b3, z3, s);
+		}
+		a = na;
+		b = nb;
+	}
+}
+
 // groups g0, g0+gs, g0+2gs, ... of one slice (gs = 1: the whole slice, in order)
 template <typename T, int MODE, bool NT>
 __device__ __forceinline__ T
@@ -266,6 +347,13 @@ sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ v
 	T s = 0;
 	int g = g0;
 	const int last = groups - 1;            // the last group holds `rem` (1..4) steps
+	if constexpr (MODE == 1 || MODE == 2)
+	{
+		const int full = rem == 4 ? groups : last;
+		const int n = full > g0 ? (full - g0 + gs - 1) / gs : 0;
+		sell_delta_piped<T, MODE, NT>(ip, vp, lane, x, s, g0, gs, n);
+		g = g0 + n * gs;
+	}
 	for (; g + gs < (rem == 4 ? groups : last); g += 2 * gs)    // 8 steps in flight per trip
 	{
 		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);

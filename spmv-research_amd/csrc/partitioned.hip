@@ -140,7 +140,10 @@ destroy_parts(spmv_mi355x_partitioned * P)
 	P->parts.clear();
 }
 
-// the exchange of one SpMV: every device ends up with all slices in its x_full. Enqueued on the parts' `comm` streams.
+// The exchange of one SpMV: afterwards every device holds all slices in its x_full. Enqueued on the parts' `comm` streams.
+// RCCL: one ncclAllGather per device inside ONE group call (the single-thread use of a single-process communicator set);
+// copies: every part PULLS the other parts' slices into its own x_full — it only ever writes its own buffer, so the ordering
+// against its own kernels is all that is needed.
 static int
 exchange_x(spmv_mi355x_partitioned * P)
 {
@@ -164,8 +167,6 @@ exchange_x(spmv_mi355x_partitioned * P)
 		}
 		return 0;
 	}
-	// peer copies: every part PULLS the other parts' slices into its own x_full on its own comm stream (it only ever writes
-	// its own buffer, so the ordering against its own kernels is all that is needed)
 	for (int p = 0; p < P->nparts; p++)
 	{
 		Part & a = P->parts[p];
@@ -188,7 +189,9 @@ exchange_x(spmv_mi355x_partitioned * P)
 	return 0;
 }
 
-// one y = A x with everything device-resident: enqueue only
+// One y = A x with everything device-resident: enqueue only, from the calling thread (about ten API calls per device and step:
+// at 8 devices that is of the order of the GPUs' own ~0.2 ms — if the driver's run shows the host as the limit, the per-device
+// sequences are the thing to capture in hipGraphs).
 static int
 step(spmv_mi355x_partitioned * P)
 {
