@@ -23,6 +23,11 @@ import time
 import numpy as np
 
 
+class VariantUnavailable(Exception):
+    """Raised on EVERY rank together (the decision went through an all-reduce): this variant's exchange did not validate on this
+    backend; the run goes on with the other variant."""
+
+
 class Source:
     """The global matrix as far as a rank needs it: sizes, the global row_ptr, and generators for row blocks / row lists."""
 
@@ -182,7 +187,11 @@ class RowsVariant:
             dist.all_gather_into_tensor(self.x_full, self.x_send)
             torch.cuda.synchronize()
             if not torch.equal(self.x_full, x_expect):
-                raise SystemExit("allgather(x) did not produce the expected padded vector")
+                ok = False
+            else:
+                ok = True
+            if not _all_agree(dist, torch, ok):
+                raise VariantUnavailable("allgather(x) did not produce the expected padded vector")
         if self.exchange != "allgather":
             ok = True
             try:
@@ -315,7 +324,7 @@ class GraphVariant:
             if _all_agree(dist, torch, ok):
                 break
         else:
-            raise SystemExit("the packed halo exchange did not validate on every rank")
+            raise VariantUnavailable("the packed halo exchange did not validate on every rank")
         del mine_dev
         t0 = time.time()
         self.launches = []
@@ -482,13 +491,18 @@ def run(args, B):
         if plan[1] == "rows" and args.exchange == "allgather":
             plan.pop()
 
-    results, order_run = {}, []
+    results, order_run, unavailable = {}, [], {}
     for name in plan:
         t0 = time.time()
-        if name == "graph+halo":
-            v = GraphVariant(c, owner, volume, args.halo)
-        else:
-            v = RowsVariant(c, "allgather" if name == "rows+allgather" else args.exchange)
+        try:
+            if name == "graph+halo":
+                v = GraphVariant(c, owner, volume, args.halo)
+            else:
+                v = RowsVariant(c, "allgather" if name == "rows+allgather" else args.exchange)
+        except VariantUnavailable as e:
+            unavailable[name] = str(e)
+            torch.cuda.empty_cache()
+            continue
         v.info["considered_max_remote_x_entries"] = considered
         r = _measure(B, v, c, args.steps, args.warmup)
         r.update(parallelism=v.describe(), partition=v.info, exchange=v.exchange_info, setup_s=round(time.time() - t0, 2),
@@ -501,6 +515,8 @@ def run(args, B):
         v.close()
         del v
         torch.cuda.empty_cache()
+    if not order_run:
+        raise SystemExit(f"no variant of the multi-GPU step validated its exchange: {unavailable}")
     best = min(order_run, key=lambda k: results[k]["ms_per_step"])
     r = results[best]
     ms = r["ms_per_step"]
@@ -541,6 +557,7 @@ def run(args, B):
         "breakdown_ms": {"exchange_alone": round(r["comm_ms"], 4), "kernels_alone": round(r["kern_ms"], 4),
                          "overlap_efficiency": round((r["comm_ms"] + r["kern_ms"]) / ms, 3)},
         "variants": {k: summary(k) for k in order_run},
+        "variants_unavailable": unavailable,
         "setup_s": {"source": round(t_src, 2), "partition": round(t_part, 2), "max_host_rss_gib_over_ranks": round(rss, 2)},
     }
     dist.barrier()
