@@ -31,8 +31,14 @@ def variants(dts):
             v.append(("csr_stream", {"stream_mode": 4, "lanes_per_row": g, "merge_items": k}))
     for i in (5, 7, 9, 11, 13):
         v.append(("csr_merge", {"merge_items": i}))
-    for c in (16, 32, 64):
-        v.append(("sell_c_sigma", {"sell_c": c}))
+    for c in (16, 32, 64, 256):
+        v.append(("sell_c_sigma", {"sell_c": c, "sell_window": 2}))
+    for sp, ng in ((4, 1), (4, 2), (4, 4), (2, 4), (2, 8), (1, 8), (1, 16)):
+        v.append(("sell_c_sigma", {"sell_window": 1, "sell_split": sp, "sell_group": ng}))
+    v.append(("sell_c_sigma", {"sell_window": 2}))                                 # delta layout where the window layout would be taken
+    v.append(("csr_scalar", {"kahan": 1}))
+    v.append(("csr_merge", {"col_blocks": -1}))
+    v.append(("csr_merge", {"col_blocks": -2}))
     v.append(("sell_c_sigma", {"sell_c": 64, "sell_delta": 2}))
     for sp in (1, 2, 4):
         v.append(("sell_c_sigma", {"sell_c": 64, "sell_split": sp}))
@@ -87,7 +93,7 @@ def main():
                         try:
                             M = E.Matrix(A["row_ptr"], A["col_idx"], A["values"], m, n, fmt, npd, **oo)
                         except Exception as e:
-                            print("skip", fmt, oo, e)
+                            print("skip", fmt, oo, str(e)[:120])
                             continue
                         s = torch.cuda.current_stream().cuda_stream
                         # warm up for >= 0.25 s (clocks, caches; the reference warms GPU kernels with 1000 calls), then the
