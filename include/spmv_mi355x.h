@@ -26,6 +26,7 @@
 #ifndef SPMV_MI355X_H
 #define SPMV_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -95,6 +96,9 @@ typedef struct {
 	int  kahan;             /* CSR_SCALAR: 1 = Kahan-compensated row sums, the reference's CUSTOM_KAHAN build (csr.cpp:353-373); same
 	                           operations in the same order -> bit-identical to it                                             */
 	int  sell_group;        /* sell_window: slices per workgroup (1, 2, 4, 8 or 16; times sell_split at most 16 wavefronts); 0 = auto */
+	int  placement;         /* where y, x and the index arrays live relative to the value array ("output vectors placed by the
+	                           engine" below): 0 = auto (a tuning pass of ~250 launches at the first use of the handle's own
+	                           vectors when y is 32 MiB or more), 2 = off                                                        */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */
@@ -142,9 +146,23 @@ int  spmv_mi355x_kernel_info(const spmv_mi355x_matrix * A, char * name_out, long
  * the distributed solver callbacks) move a vector slice into its exchange buffer. */
 int  spmv_mi355x_copy_device_async(void * dst_dev, const void * src_dev, long bytes, void * hip_stream);
 
-/* Device buffers owned by the handle (allocated lazily by the host-buffer entry points). */
+/* Device buffers owned by the handle (allocated lazily by the host-buffer entry points): x has n values, y has rows + 64
+ * (the reference driver's slack, bench_spmv.cpp:606-609). y is placed as an OUTPUT vector (below). */
 void * spmv_mi355x_x_device(spmv_mi355x_matrix * A);
 void * spmv_mi355x_y_device(spmv_mi355x_matrix * A);
+int  spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host);      /* rows values into the handle's y (for y += A x) */
+
+/* ---- output vectors placed by the engine -------------------------------------------------------------------------- */
+/* The 288 GiB of an MI355X behave as 32 GiB regions, and the same kernel on the same matrix and x takes 1.28, 1.30 or 1.42 ms
+ * (nlpkkt240 twin) depending only on which region y lives in; which memory an allocation gets is the driver's choice
+ * (profiles/r02_placement.md). A vector the handle's SpMV writes is therefore placed by timing the handle's own
+ * kernel on it: when a candidate from deeper in the pool is clearly faster, it replaces the first one. The handle's own y
+ * (spmv_mi355x_y_device, used by spmv_mi355x_spmv) is placed this way; output_alloc gives callers of the device-pointer entry
+ * points the same for their vectors (bytes >= (rows + 64) values; smaller or < 32 MiB: a plain allocation). Zero-filled.
+ * SPMV_MI355X_PLACEMENT=0 turns the search off, =2 reports it on stderr. No reference counterpart (the reference's GPU
+ * backends hipMalloc their vectors in the constructor, GPU_clean/csr_rocm_vector.cpp:77-86). */
+int  spmv_mi355x_output_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out);
+int  spmv_mi355x_output_free(void * p);
 
 /* ---- solver callers of spmv() ---------------------------------------------------------------- */
 /* Device-resident replacements for the reference's two Krylov drivers, which call MF->spmv() with a vector that changes

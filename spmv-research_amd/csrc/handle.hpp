@@ -72,8 +72,13 @@ struct spmv_mi355x_matrix {
 	// host-buffer path
 	void * d_x = nullptr;
 	void * d_y = nullptr;
+	bool placement_off = false;            // opts.placement == 2
+	struct PlacedBlock { void * base; size_t bytes; };
+	std::vector<PlacedBlock> placed_blocks;   // placement.hip: allocations that now hold several of the arrays above
 	const void * cached_x_host = nullptr;
 	bool y_downloaded = false;
+	double place_fast_us = 0;         // placement.hip: kernel time on an output vector known to sit in a fast region
+	double place_only_us = 0;         //                the one time a complete walk saw
 	bool always_copy = false;
 	hipStream_t stream = nullptr;
 
@@ -88,6 +93,9 @@ namespace spmv {
 
 // ---- device memory helpers (handle.hip)
 int dev_alloc_bytes(void ** p, size_t bytes);
+int ensure_x(spmv_mi355x_matrix * A);                                    // spmv_mi355x.hip: stream + the handle's own (zeroed) x
+int tune_placement(spmv_mi355x_matrix * A);                              // placement.hip: move y, x and the side arrays to better blocks of HBM
+int dev_alloc_output(spmv_mi355x_matrix * A, void ** p, size_t bytes);   // placement.hip: a vector A's SpMV writes (placed by timing, zero-filled)
 template <typename T>
 inline int
 dev_alloc(T ** p, size_t count)

@@ -68,7 +68,7 @@ struct Part {
 	long r0 = 0, r1 = 0;
 	spmv_mi355x_matrix * loc = nullptr;    // columns inside the own slice of x
 	spmv_mi355x_matrix * rem = nullptr;    // columns owned by the other parts
-	void * x_full = nullptr;               // nparts padded slices
+	void * x_full = nullptr;               // nparts padded slices; x_full and y are the own (engine-placed) x / y pair of `loc`
 	void * y = nullptr;                    // the part's rows of y (+64 slack, as the driver's y)
 	hipStream_t comp = nullptr, comm = nullptr;
 	hipEvent_t x_ready = nullptr, done = nullptr;
@@ -130,8 +130,6 @@ destroy_parts(spmv_mi355x_partitioned * P)
 		(void) hipSetDevice(p.device);
 		if (p.loc) spmv_mi355x_destroy(p.loc);
 		if (p.rem) spmv_mi355x_destroy(p.rem);
-		if (p.x_full) (void) hipFree(p.x_full);
-		if (p.y) (void) hipFree(p.y);
 		if (p.comp) (void) hipStreamDestroy(p.comp);
 		if (p.comm) (void) hipStreamDestroy(p.comm);
 		if (p.x_ready) (void) hipEventDestroy(p.x_ready);
@@ -359,7 +357,14 @@ spmv_mi355x_create_partitioned(spmv_mi355x_partitioned ** out, int nparts, const
 		rc = spmv_mi355x_create(&a.loc, format, precision, lm, n_x, lnnz, l_rp.data(), l_ci.data(), values + e0, &po);
 		po.col_filter_mode = 2;
 		rc = rc || spmv_mi355x_create(&a.rem, format, precision, lm, n_x, lnnz, l_rp.data(), l_ci.data(), values + e0, &po);
-		rc = rc || dev_alloc_bytes(&a.x_full, (size_t) n_x * P->vbytes) || dev_alloc_bytes(&a.y, (size_t) (lm + 64) * P->vbytes);
+		if (!rc)
+		{
+			// the local-column handle has n_x columns and lm rows: its own x / y pair (placed relative to its arrays,
+			// placement.hip) is exactly this part's x_full and y
+			a.x_full = spmv_mi355x_x_device(a.loc);
+			a.y = spmv_mi355x_y_device(a.loc);
+			rc = !a.x_full || !a.y;
+		}
 		if (rc)
 			break;
 		if (hipMemset(a.x_full, 0, (size_t) n_x * P->vbytes) != hipSuccess || hipStreamCreate(&a.comp) != hipSuccess ||

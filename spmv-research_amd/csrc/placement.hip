@@ -1,0 +1,350 @@
+// Placement of the vectors beside the matrix in HBM.
+//
+// Measured on MI355X (profiles/r02_placement.md): the 288 GiB of a device behave as 32 GiB blocks that fall into classes, and the
+// SAME SpMV kernel on the SAME matrix and x takes 1.25-1.29 ms or 1.46 ms (nlpkkt240 twin) depending only on whether y sits in
+// a block of the same class as the value array (y is 2.6 % of the traffic: ~100 ns per written line, a DRAM row conflict per
+// write-back); x and the index arrays move the time by 1-5 % the same way. Offsets inside a block do not matter. Which physical
+// memory an allocation gets is the driver's choice and differs from process to process; a process that allocates its handle and
+// then its vectors gets them side by side, usually in one block — the "slow timing state" round 1 could not explain.
+// Synthetic write probes rank the blocks differently from the SpMV kernel, so vectors are placed by timing the handle's OWN
+// kernel on candidates taken from deeper and deeper in the pool: earlier candidates and 16 GiB of ballast per step stay allocated
+// during the walk so that the driver has to move on, and everything but the winner is returned at the end.
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <vector>
+
+#include "handle.hpp"
+
+namespace spmv {
+
+namespace {
+
+constexpr size_t PLACE_MIN_BYTES = (size_t) 32 << 20;      // smaller outputs stay in the caches: nothing to place
+constexpr size_t BALLAST_STEP = (size_t) 16 << 30;         // blocks are 32 GiB: two candidates per block
+constexpr size_t WALK_LIMIT = (size_t) 160 << 30;
+constexpr size_t KEEP_FREE = (size_t) 8 << 30;             // never take the last of the pool for ballast
+constexpr double CONTRAST = 1.04;                          // classes differ by 12-15 % (the two fast ones by 3 %), repeats by < 0.3 %
+
+int
+setting()
+{
+	static const int s = getenv("SPMV_MI355X_PLACEMENT") ? atoi(getenv("SPMV_MI355X_PLACEMENT")) : 1;
+	return s;
+}
+
+// average microseconds of the handle's kernel reading x and writing y
+double
+kernel_us(spmv_mi355x_matrix * A, const void * x, void * y)
+{
+	double ms = 0;
+	if (spmv_mi355x_time_device(A, x, y, 2, A->stream, &ms))         // warm-up: first touch of the candidate
+		return -1.0;
+	if (spmv_mi355x_time_device(A, x, y, 4, A->stream, &ms))
+		return -1.0;
+	return ms * 1e3;
+}
+
+struct Walk {
+	double t_first = 0, t_chosen = 0, seconds = 0;
+	int tries = 1;
+	bool known = false;
+};
+
+// `first` (already allocated, `bytes` long) or a better-placed replacement of it in *chosen; measure(candidate) = kernel
+// microseconds with the candidate in use. The caller moves contents and frees `first` when it lost.
+template <typename Measure>
+int
+walk(spmv_mi355x_matrix * A, void * first, size_t bytes, Measure measure, void ** chosen, Walk & w)
+{
+	const auto c0 = std::chrono::steady_clock::now();
+	*chosen = first;
+	w.t_first = w.t_chosen = measure(first);
+	if (w.t_first < 0)
+		return 1;
+	std::vector<void *> held;              // ballast and rejected candidates, returned at the end
+	w.known = A->place_fast_us > 0 && w.t_first <= A->place_fast_us * CONTRAST;
+	if (!w.known && A->place_only_us > 0 && A->place_fast_us == 0)
+	{
+		if (w.t_first * CONTRAST < A->place_only_us)       // faster than everything a whole walk saw
+		{
+			A->place_fast_us = w.t_first;
+			w.known = true;
+		}
+		else if (w.t_first <= A->place_only_us * CONTRAST)
+			w.known = true;
+	}
+	if (!w.known)
+	{
+		bool contrast = false;
+		for (size_t walked = 0; walked < WALK_LIMIT; walked += BALLAST_STEP)
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < BALLAST_STEP + bytes + KEEP_FREE)
+				break;
+			void * ballast = nullptr, * cand = nullptr;
+			if (hipMalloc(&ballast, BALLAST_STEP) != hipSuccess)
+			{
+				(void) hipGetLastError();
+				break;
+			}
+			held.push_back(ballast);
+			if (hipMalloc(&cand, bytes) != hipSuccess)
+			{
+				(void) hipGetLastError();
+				break;
+			}
+			(void) hipMemset(cand, 0, bytes);
+			const double t = measure(cand);
+			w.tries++;
+			if (t > 0 && t * CONTRAST < w.t_chosen)
+			{
+				if (*chosen != first)
+					held.push_back(*chosen);
+				*chosen = cand;                  // what was held so far shares a block class with the value stream
+				w.t_chosen = t;
+				A->place_fast_us = t;
+				contrast = true;
+				break;
+			}
+			held.push_back(cand);
+			if (t > w.t_chosen * CONTRAST)          // what is held so far is well placed
+			{
+				A->place_fast_us = w.t_chosen;
+				contrast = true;
+				break;
+			}
+		}
+		if (!contrast && A->place_fast_us == 0)
+			A->place_only_us = w.t_first;
+	}
+	for (void * p : held)
+		(void) hipFree(p);
+	w.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+	return 0;
+}
+
+void
+report(const char * what, size_t bytes, const Walk & w)
+{
+	if (setting() >= 2)
+		fprintf(stderr, "[spmv_mi355x] placed %s (%.0f MiB): %.1f us per SpMV on the first candidate, %.1f us on the chosen one, %d candidate(s)%s, %.0f ms\n",
+				what, (double) bytes / (1 << 20), w.t_first, w.t_chosen, w.tries, w.known ? " (rate already known)" : "", w.seconds * 1e3);
+}
+
+// Diagnostic (SPMV_MI355X_PLACEMENT=4): the kernel time with the value array at arena + a*16 GiB and y at arena + (b*16 + 8) GiB
+// of one 160 GiB allocation, a, b = 0..9 — the table of profiles/r02_placement.md §4
+int
+placement_map(spmv_mi355x_matrix * A)
+{
+	size_t vsize = 0;
+	if (!A->d_val || hipMemPtrGetInfo(A->d_val, &vsize) != hipSuccess || vsize > ((size_t) 8 << 30))
+	{
+		(void) hipGetLastError();
+		return 0;
+	}
+	const size_t G = (size_t) 1 << 30;
+	const int NA = 10;
+	void * arena = nullptr;
+	HIP_TRY(hipMalloc(&arena, NA * 16 * G));
+	void * val0 = A->d_val;
+	fprintf(stderr, "[spmv_mi355x] rows: value array (%.1f GiB) at a*16 GiB; columns: y at b*16+8 GiB; kernel us\n", (double) vsize / G);
+	for (int a = 0; a < NA; a++)
+	{
+		void * v = (char *) arena + (size_t) a * 16 * G;
+		HIP_TRY(hipMemcpy(v, val0, vsize, hipMemcpyDeviceToDevice));
+		A->d_val = v;
+		fprintf(stderr, "[spmv_mi355x] a=%d:", a);
+		for (int b = 0; b < NA; b++)
+			fprintf(stderr, " %6.0f", kernel_us(A, A->d_x, (char *) arena + ((size_t) b * 16 + 8) * G));
+		fprintf(stderr, "\n");
+	}
+	A->d_val = val0;
+	HIP_TRY(hipFree(arena));
+	return 0;
+}
+
+}   // namespace
+
+// One pass of coordinate descent over WHERE the handle's arrays live. The largest array (the value stream) stays; every other
+// array of 16 MiB .. 1 GiB (y, x, index bytes, row permutation, ...) is tried at up to ten sites taken 16 GiB apart from the pool
+// (a D2D copy and six launches per trial) and stays at the site where the handle's kernel ran fastest, if that beats where it
+// was by 1 %. Sites that end up unused, the ballast between them and the originals of moved arrays are returned.
+int
+tune_placement(spmv_mi355x_matrix * A)
+{
+	if (setting() == 0 || A->placement_off || !A->d_x || !A->d_y || (size_t) (A->m + 64) * A->vbytes < PLACE_MIN_BYTES)
+		return 0;
+	const auto c0 = std::chrono::steady_clock::now();
+	struct Slot { void ** p; const char * name; size_t size, off; };
+	Slot all[] = {{&A->d_y, "y", 0, 0}, {&A->d_x, "x", 0, 0}, {&A->d_val, "val", 0, 0}, {(void **) &A->d_sell_idx, "sell_idx", 0, 0},
+	              {(void **) &A->d_col, "col", 0, 0}, {(void **) &A->d_row_of_sorted, "row_of_sorted", 0, 0}, {(void **) &A->d_coob_ent, "coob_ent", 0, 0},
+	              {(void **) &A->d_row_ptr, "row_ptr", 0, 0}, {(void **) &A->d_col16, "col16", 0, 0}, {(void **) &A->d_sell_desc, "sell_desc", 0, 0},
+	              {(void **) &A->d_slice_ptr, "slice_ptr", 0, 0}, {(void **) &A->d_rowind, "rowind", 0, 0}};
+	size_t largest = 0;
+	for (Slot & sl : all)
+		if (*sl.p)
+		{
+			if (hipMemPtrGetInfo(*sl.p, &sl.size) != hipSuccess)
+			{
+				(void) hipGetLastError();
+				sl.size = 0;
+			}
+			largest = std::max(largest, sl.size);
+		}
+	std::vector<Slot *> movable;
+	size_t site_bytes = 0;
+	bool anchored = false;
+	for (Slot & sl : all)
+	{
+		if (sl.size == largest && !anchored && sl.p != &A->d_y && sl.p != &A->d_x)
+		{
+			anchored = true;                        // the big stream everything else is placed against
+			continue;
+		}
+		if (sl.size >= ((size_t) 16 << 20) && sl.size <= ((size_t) 1 << 30))
+		{
+			sl.off = site_bytes;
+			site_bytes += (sl.size + ((size_t) 2 << 20) - 1) / ((size_t) 2 << 20) * ((size_t) 2 << 20);
+			movable.push_back(&sl);
+		}
+	}
+	if (!anchored || movable.empty())
+		return 0;
+	std::vector<void *> ballast, sites;
+	for (int s = 0; s < 10; s++)
+	{
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < BALLAST_STEP + site_bytes + KEEP_FREE)
+			break;
+		void * b = nullptr, * site = nullptr;
+		if (hipMalloc(&b, BALLAST_STEP) != hipSuccess)
+		{
+			(void) hipGetLastError();
+			break;
+		}
+		ballast.push_back(b);
+		if (hipMalloc(&site, site_bytes) != hipSuccess)
+		{
+			(void) hipGetLastError();
+			break;
+		}
+		sites.push_back(site);
+	}
+	const double ms_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3;
+	std::vector<int> used(sites.size(), 0);
+	std::vector<void *> to_free;
+	double t_cur = kernel_us(A, A->d_x, A->d_y);
+	const double t_start = t_cur;
+	int rc = t_cur < 0;
+	for (Slot * sl : movable)
+	{
+		if (rc)
+			break;
+		void * const orig = *sl->p;
+		int best = -1;
+		double t_best = t_cur;
+		if (setting() >= 2)
+			fprintf(stderr, "[spmv_mi355x] %-14s %5.0f MiB: %7.1f us where it is; at the sites:", sl->name, (double) sl->size / (1 << 20), t_cur);
+		for (size_t s = 0; s < sites.size() && !rc; s++)
+		{
+			void * dst = (char *) sites[s] + sl->off;
+			if (hipMemcpy(dst, orig, sl->size, hipMemcpyDeviceToDevice) != hipSuccess)
+			{
+				set_error("placement: device copy failed: %s", hipGetErrorString(hipGetLastError()));
+				rc = 1;
+				break;
+			}
+			*sl->p = dst;
+			const double t = kernel_us(A, A->d_x, A->d_y);
+			if (t < 0)
+				rc = 1;
+			if (setting() >= 2)
+				fprintf(stderr, " %.0f", t);
+			if (t > 0 && t < t_best * 0.99)
+			{
+				best = (int) s;
+				t_best = t;
+			}
+		}
+		if (best >= 0 && !rc)
+		{
+			*sl->p = (char *) sites[(size_t) best] + sl->off;
+			used[(size_t) best] = 1;
+			to_free.push_back(orig);
+			t_cur = t_best;
+		}
+		else
+			*sl->p = orig;
+		if (setting() >= 2)
+			fprintf(stderr, " -> %s, %.1f us\n", best >= 0 ? "moved" : "stays", t_cur);
+	}
+	if (!rc)
+		HIP_TRY(hipMemset(A->d_y, 0, (size_t) (A->m + 64) * A->vbytes));
+	for (void * p : ballast)
+		(void) hipFree(p);
+	for (void * p : to_free)
+		(void) hipFree(p);
+	for (size_t s = 0; s < sites.size(); s++)
+		if (used[s])
+			A->placed_blocks.push_back({sites[s], site_bytes});
+		else
+			(void) hipFree(sites[s]);
+	A->place_fast_us = t_cur;                      // later output vectors are held against this
+	if (setting() >= 2)
+		fprintf(stderr, "[spmv_mi355x] placement: %.1f -> %.1f us per SpMV, %zu sites, %.0f ms (%.0f ms of it allocating the sites)\n", t_start, t_cur,
+				sites.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3, ms_alloc);
+	if (!rc && setting() == 4)
+		return placement_map(A);
+	return rc;
+}
+
+// allocation of `bytes` for a vector the handle's SpMV writes (A->d_x must exist). Zero-filled.
+int
+dev_alloc_output(spmv_mi355x_matrix * A, void ** out, size_t bytes)
+{
+	if (dev_alloc_bytes(out, bytes))
+		return 1;
+	HIP_TRY(hipMemset(*out, 0, std::max<size_t>(bytes, 8)));
+	const size_t need = (size_t) (A->m + 64) * A->vbytes;
+	if (setting() == 0 || A->placement_off || bytes < PLACE_MIN_BYTES || bytes < need || !A->d_x)
+		return 0;
+	void * first = *out, * chosen = nullptr;
+	Walk w;
+	if (walk(A, first, bytes, [&](void * c) { return kernel_us(A, A->d_x, c); }, &chosen, w))
+		return 1;
+	if (chosen != first)
+		HIP_TRY(hipFree(first));
+	HIP_TRY(hipMemset(chosen, 0, bytes));
+	*out = chosen;
+	report("an output vector", bytes, w);
+	return 0;
+}
+
+}   // namespace spmv
+
+extern "C" {
+
+int
+spmv_mi355x_output_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out)
+{
+	if (!A || !out)
+	{
+		spmv::set_error("output_alloc: NULL argument");
+		return 1;
+	}
+	*out = nullptr;
+	if (spmv::ensure_x(A))                   // sets the device, creates the handle's stream and its own x
+		return 1;
+	return spmv::dev_alloc_output(A, out, bytes);
+}
+
+int
+spmv_mi355x_output_free(void * p)
+{
+	if (p)
+		HIP_TRY(hipFree(p));
+	return 0;
+}
+
+}

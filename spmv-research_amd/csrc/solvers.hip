@@ -33,6 +33,7 @@
 
 namespace spmv {
 
+
 constexpr int VB = 256;           // threads per block of the vector kernels
 constexpr int MAX_PART = 1024;    // partial sums per quantity
 constexpr int RESTART_K = 100;    // bench_cg.cpp:178
@@ -492,6 +493,20 @@ struct DeviceBuffers {
 		*out = (P *) p;
 		return 0;
 	}
+	template <typename P>
+	int alloc_output(spmv_mi355x_matrix * A, P ** out, size_t bytes)         // a vector A's SpMV writes: placed by the engine
+	{
+		void * p = nullptr;
+		if (A ? spmv_mi355x_output_alloc(A, bytes, &p) : (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess))
+		{
+			if (!A)
+				set_error("hipMalloc of %zu bytes failed", bytes);
+			return 1;
+		}
+		ptrs.push_back(p);
+		*out = (P *) p;
+		return 0;
+	}
 };
 
 // Jacobi preconditioner: the first stored entry of row i whose column is i (bench_cg.cpp:114-134).
@@ -549,11 +564,15 @@ solve(int method, spmv_mi355x_matrix * A, const spmv_mi355x_dist_ops * dist, lon
 
 	T * b, * K, * x, * x_best, * r, * r_explicit, * p, * Ap;
 	T * r0 = nullptr, * y = nullptr, * z = nullptr, * s = nullptr, * v = nullptr;
-	for (T ** q : {&b, &K, &x, &x_best, &r, &r_explicit, &p, &Ap})
+	for (T ** q : {&b, &K, &x, &x_best, &r, &r_explicit, &p})
 		ABI_TRY(buf.alloc(q, vb));
+	ABI_TRY(buf.alloc_output(dist ? nullptr : A, &Ap, vb + 64 * sizeof(T)));                          // the SpMV outputs
 	if (method == 1)
-		for (T ** q : {&r0, &y, &z, &s, &v})
+	{
+		for (T ** q : {&r0, &y, &z, &s})
 			ABI_TRY(buf.alloc(q, vb));
+		ABI_TRY(buf.alloc_output(dist ? nullptr : A, &v, vb + 64 * sizeof(T)));
+	}
 	double * part, * history = nullptr;
 	SolverState * st;
 	ABI_TRY(buf.alloc(&part, sizeof(double) * NUM_SLOTS * MAX_PART));

@@ -17,6 +17,22 @@ set_error(const char * fmt, ...)
 	va_end(ap);
 }
 
+// the handle's stream and its own (zeroed) input vector
+int
+ensure_x(spmv_mi355x_matrix * A)
+{
+	HIP_TRY(hipSetDevice(A->device));
+	if (!A->stream)
+		HIP_TRY(hipStreamCreate(&A->stream));
+	if (!A->d_x)
+	{
+		if (dev_alloc_bytes(&A->d_x, (size_t) std::max<long>(A->n, 1) * A->vbytes))
+			return 1;
+		HIP_TRY(hipMemset(A->d_x, 0, (size_t) std::max<long>(A->n, 1) * A->vbytes));
+	}
+	return 0;
+}
+
 }  // namespace spmv
 
 using namespace spmv;
@@ -124,6 +140,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 	A->f32 = (precision == SPMV_MI355X_F32);
 	A->vbytes = A->f32 ? 4 : 8;
 	A->device = device;
+	A->placement_off = o.placement == 2;
 	A->n = n;
 	A->m = in.m;
 	A->nnz = in.nnz;
@@ -298,13 +315,16 @@ spmv_mi355x_kernel_info(const spmv_mi355x_matrix * A, char * name_out, long name
 static int
 ensure_xy(spmv_mi355x_matrix * A)
 {
-	HIP_TRY(hipSetDevice(A->device));
-	if (!A->stream)
-		HIP_TRY(hipStreamCreate(&A->stream));
-	if (!A->d_x && dev_alloc_bytes(&A->d_x, (size_t) std::max<long>(A->n, 1) * A->vbytes))
+	if (ensure_x(A))
 		return 1;
-	if (!A->d_y && dev_alloc_bytes(&A->d_y, (size_t) (A->m + 64) * A->vbytes))
-		return 1;
+	if (!A->d_y)
+	{
+		if (dev_alloc_bytes(&A->d_y, (size_t) (A->m + 64) * A->vbytes))
+			return 1;
+		HIP_TRY(hipMemset(A->d_y, 0, (size_t) (A->m + 64) * A->vbytes));
+		if (tune_placement(A))              // placement.hip: once, now that every array of the handle exists
+			return 1;
+	}
 	return 0;
 }
 
@@ -326,6 +346,16 @@ spmv_mi355x_upload_x(spmv_mi355x_matrix * A, const void * x_host)
 	HIP_TRY(hipMemcpyAsync(A->d_x, x_host, (size_t) A->n * A->vbytes, hipMemcpyHostToDevice, A->stream));
 	HIP_TRY(hipStreamSynchronize(A->stream));
 	A->cached_x_host = x_host;
+	return 0;
+}
+
+int
+spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host)
+{
+	if (ensure_xy(A))
+		return 1;
+	HIP_TRY(hipMemcpyAsync(A->d_y, y_host, (size_t) A->m * A->vbytes, hipMemcpyHostToDevice, A->stream));
+	HIP_TRY(hipStreamSynchronize(A->stream));
 	return 0;
 }
 

@@ -155,7 +155,9 @@ class RowsVariant:
         self._fill_own()
         # RCCL gathers in place (send buffer = own slice of the receive buffer); gloo stages through the host and wants a separate one
         self.x_send = self.x_loc if c.args.backend == "nccl" else self.x_loc.clone()
-        self.y = torch.full((lm + 64,), 1.0, dtype=c.t_dtype, device="cuda")
+        self.y_vec = self.mats[0].output_vector(lm + 64)        # placed by the engine relative to the handle's arrays (csrc/placement.hip)
+        self.y = self.y_vec.torch()
+        self.y.fill_(1.0)
         self.use_p2p, self.exch = False, None
         self.info = {"kind": "rows"}
         self.exchange_info = {"chosen": "allgather"}
@@ -265,6 +267,9 @@ class RowsVariant:
             M.close()
         self.mats = []
         self.x_full = self.x_loc = self.x_send = self.y = self.blk = self.exch = None
+        if getattr(self, "y_vec", None) is not None:
+            self.y_vec.free()
+            self.y_vec = None
 
 
 class GraphVariant:
@@ -340,7 +345,9 @@ class GraphVariant:
             del b
         self.mats = [l[0] for l in self.launches]
         self.t_conv = time.time() - t0
-        self.y = torch.full((self.lm + 64,), 1.0, dtype=c.t_dtype, device="cuda")
+        self.y_vec = self.mats[0].output_vector(self.lm + 64)   # placed by the engine relative to the first block's arrays
+        self.y = self.y_vec.torch()
+        self.y.fill_(1.0)
         self.exchange_info = {"chosen": "packed halo " + self.packed.mode, "recv_x_entries": self.packed.recv_elems,
                               "send_x_entries": self.packed.send_elems, "recv_max_from_one_peer": self.packed.recv_max_from_one_peer}
 
@@ -376,6 +383,9 @@ class GraphVariant:
             M.close()
         self.mats, self.launches = [], []
         self.x_full = self.y = self.packed = None
+        if getattr(self, "y_vec", None) is not None:
+            self.y_vec.free()
+            self.y_vec = None
 
 
 class Ctx:

@@ -27,7 +27,7 @@ class Opts(C.Structure):
                 ("row_begin", C.c_long), ("row_end", C.c_long), ("col_begin", C.c_long), ("col_end", C.c_long),
                 ("col_filter_mode", C.c_int), ("sell_delta", C.c_int), ("convert_on", C.c_int),
                 ("symmetric_input", C.c_int), ("rows_per_group", C.c_int), ("col_blocks", C.c_int),
-                ("sell_window", C.c_int), ("kahan", C.c_int), ("sell_group", C.c_int)]
+                ("sell_window", C.c_int), ("kahan", C.c_int), ("sell_group", C.c_int), ("placement", C.c_int)]
 
 
 # every symbol declared in include/spmv_mi355x.h (checked by tests/test_abi.py)
@@ -44,6 +44,7 @@ SYMBOLS = [
     "spmv_mi355x_partitioned_set_always_copy", "spmv_mi355x_time_partitioned", "spmv_mi355x_partitioned_parts",
     "spmv_mi355x_partitioned_offsets", "spmv_mi355x_partitioned_format_name", "spmv_mi355x_partitioned_exchange",
     "spmv_mi355x_partitioned_mem_footprint",
+    "spmv_mi355x_upload_y", "spmv_mi355x_output_alloc", "spmv_mi355x_output_free",
 ]
 
 _lib = None
@@ -102,6 +103,42 @@ def device_info(device=0):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class OutputVector:
+    """A device vector a handle's SpMV writes, allocated by the engine (include/spmv_mi355x.h "output vectors placed by the
+    engine"): placed by timing the handle's own kernel on it. `.ptr` goes to spmv_device(); `.torch()` is a zero-copy torch
+    view (CUDA array interface) for callers that fill / check it with torch."""
+
+    def __init__(self, matrix, count):
+        self.count, self.dtype = int(count), np.dtype(matrix.dtype)
+        self.nbytes = max(self.count, 1) * self.dtype.itemsize
+        out = C.c_void_p()
+        _check(lib().spmv_mi355x_output_alloc(matrix.h, C.c_size_t(self.nbytes), C.byref(out)))
+        self.ptr = out.value
+        self._view = None
+
+    @property
+    def __cuda_array_interface__(self):
+        return dict(shape=(self.count,), typestr=self.dtype.str, data=(self.ptr, False), version=2, strides=None)
+
+    def torch(self):
+        import torch
+        if self._view is None:
+            self._view = torch.as_tensor(self, device="cuda")
+        return self._view
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self._view = None
+            lib().spmv_mi355x_output_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class SolverInfo(C.Structure):
@@ -267,6 +304,15 @@ class Matrix:
     def upload_x(self, x):
         x = np.ascontiguousarray(x, self.dtype)
         _check(lib().spmv_mi355x_upload_x(self.h, _p(x)))
+
+    def output_vector(self, count=None):
+        """An engine-placed device vector for this handle's SpMV to write (rows + 64 values by default)."""
+        return OutputVector(self, self.m + 64 if count is None else count)
+
+    def upload_y(self, y):
+        y = np.ascontiguousarray(y, self.dtype)
+        assert y.shape[0] >= self.m
+        _check(lib().spmv_mi355x_upload_y(self.h, _p(y)))
 
     def download_y(self):
         y = np.zeros(self.m, self.dtype)

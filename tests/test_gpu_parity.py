@@ -582,3 +582,55 @@ def test_merge_drops_the_value_stream_of_pattern_matrices(eng, oracle):
             check(yu, y_ref, absrow, dtype, False, f"unit merge {const} {np.dtype(dtype).name}")
             U.close()
             G.close()
+
+
+def test_engine_placed_vectors(eng, oracle):
+    """The handle's own x / y pair and an output vector from output_alloc (csrc/placement.hip): results through them equal the
+    host-buffer path; y += A x through upload_y. Small matrix: no placement search (below 32 MiB), only the plumbing."""
+    info, g = load_case("general_real")
+    rp, ci, a = g["row_ptr"], g["col_idx"], g["values"]
+    m, n = info["m"], info["n"]
+    A = eng.Matrix(rp, ci, a, m, n, "csr_vector")
+    x = np.random.default_rng(5).uniform(-1, 1, n)
+    y_ref = A.spmv(x)
+    A.upload_x(x)
+    xp, yp = A.x_device(), A.y_device()
+    assert xp and yp and xp != yp
+    A.upload_y(np.full(m, 3.0))
+    A.spmv_device(xp, yp, 1, 0)
+    np.testing.assert_allclose(A.download_y(), y_ref + 3.0, rtol=1e-13, atol=1e-13)
+    v = A.output_vector()
+    assert v.count == m + 64
+    t = v.torch()
+    assert float(t.abs().sum().item()) == 0.0          # zero-filled
+    A.spmv_device(xp, v.ptr, 0, 0)
+    import torch
+    torch.cuda.synchronize()
+    assert np.array_equal(t[:m].cpu().numpy(), y_ref)
+    v.free()
+    A.close()
+
+
+def test_placement_search_keeps_results(eng):
+    """A matrix whose y is above the 32 MiB threshold: the placement pass runs (y, x, the index arrays are tried at other sites
+    and may move) and an output vector is placed against the tuned handle; results must not change."""
+    m = 4_600_000
+    rp = np.arange(0, 3 * m + 1, 3, dtype=np.int32)
+    rows = np.arange(m, dtype=np.int64)
+    ci = np.stack([np.maximum(rows - 1, 0), rows, np.minimum(rows + 1, m - 1)], axis=1)
+    ci[0] = [0, 1, 2]
+    ci[-1] = [m - 3, m - 2, m - 1]
+    ci = ci.reshape(-1).astype(np.int32)
+    a = np.tile(np.array([0.5, 2.0, -0.25]), m)
+    A = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma")
+    x = np.random.default_rng(7).uniform(-1, 1, m)
+    v = A.output_vector()                                # before the handle's own pass (only its zeroed x exists)
+    y = A.spmv(x)                                        # runs the placement pass, uploads x
+    ref = 0.5 * x[ci[0::3]] + 2.0 * x[ci[1::3]] - 0.25 * x[ci[2::3]]
+    np.testing.assert_allclose(y, ref, rtol=1e-13, atol=1e-13)
+    A.spmv_device(A.x_device(), v.ptr, 0, 0)
+    import torch
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(v.torch()[:m].cpu().numpy(), ref, rtol=1e-13, atol=1e-13)
+    v.free()
+    A.close()

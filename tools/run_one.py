@@ -32,14 +32,14 @@ def main():
     td = torch.float64 if args.dtype == "f64" else torch.float32
     opts = {k: int(v) for k, v in (o.split("=") for o in args.opt)}
     M = E.Matrix(A["row_ptr"], A["col_idx"], A["values"], A["m"], A["n"], args.format, npd, **opts)
-    x = torch.from_numpy(np.random.default_rng(14).uniform(-1, 1, A["n"]).astype(npd)).cuda()
-    y = torch.zeros(A["m"] + 64, dtype=td, device="cuda")
+    M.upload_x(np.random.default_rng(14).uniform(-1, 1, A["n"]).astype(npd))     # the handle's own, engine-placed x / y (as bench.py)
+    xp, yp = M.x_device(), M.y_device()
     s = torch.cuda.current_stream().cuda_stream
     import time
     t_w = time.time()
     while time.time() - t_w < 0.25 and args.iters > 5:          # profiling passes use --iters <= 5 and skip the warm-up
-        M.time_device(x.data_ptr(), y.data_ptr(), args.iters, s)
-    ms = float(np.median([M.time_device(x.data_ptr(), y.data_ptr(), args.iters, s) for _ in range(5 if args.iters > 5 else 1)]))
+        M.time_device(xp, yp, args.iters, s)
+    ms = float(np.median([M.time_device(xp, yp, args.iters, s) for _ in range(5 if args.iters > 5 else 1)]))
     vb = 8 if args.dtype == "f64" else 4
     B = A["nnz"] * (vb + 4) + (A["m"] + 1) * 4 + (A["n"] + A["m"]) * vb
     print(f"{args.workload} {M.format_name} {ms*1e3:.1f} us/launch {B/ms/1e6:.1f} GB/s algorithmic_bytes={B}")

@@ -49,6 +49,14 @@ def variants(dts):
     return v
 
 
+class _Ptr:
+    def __init__(self, p):
+        self.p = p
+
+    def data_ptr(self):
+        return self.p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="cant,scircuit,pwtk,soc-LiveJournal1,nlpkkt240")
@@ -78,8 +86,7 @@ def main():
             td = torch.float64 if dts == "f64" else torch.float32
             vb = 8 if dts == "f64" else 4
             B = nnz * (vb + 4) + (m + 1) * 4 + (n + m) * vb
-            x = torch.from_numpy(np.random.default_rng(14).uniform(-1, 1, n).astype(npd)).cuda()
-            y = torch.zeros(m + 64, dtype=td, device="cuda")
+            x_host = np.random.default_rng(14).uniform(-1, 1, n).astype(npd)
             for fmt, o in variants(dts):
                 if args.formats and fmt not in args.formats.split(","):
                     continue
@@ -95,6 +102,8 @@ def main():
                         except Exception as e:
                             print("skip", fmt, oo, str(e)[:120])
                             continue
+                        M.upload_x(x_host)                       # the handle's own, engine-placed x / y (as bench.py)
+                        x, y = _Ptr(M.x_device()), _Ptr(M.y_device())
                         s = torch.cuda.current_stream().cuda_stream
                         # warm up for >= 0.25 s (clocks, caches; the reference warms GPU kernels with 1000 calls), then the
                         # median of 7 batches: single short bursts were seen to be bimodal on small matrices
