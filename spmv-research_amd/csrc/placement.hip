@@ -20,7 +20,7 @@ namespace spmv {
 
 namespace {
 
-constexpr size_t PLACE_MIN_BYTES = (size_t) 32 << 20;      // smaller outputs stay in the caches: nothing to place
+constexpr size_t PLACE_MIN_BYTES = (size_t) 8 << 20;       // smaller problems run out of the caches
 constexpr size_t BALLAST_STEP = (size_t) 16 << 30;         // blocks are 32 GiB: two candidates per block
 constexpr size_t WALK_LIMIT = (size_t) 160 << 30;
 constexpr size_t KEEP_FREE = (size_t) 8 << 30;             // never take the last of the pool for ballast
