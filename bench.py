@@ -105,6 +105,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--force-multi", action="store_true",
+                    help="run the N>1 code path with whatever WORLD_SIZE is, 1 included (tests: the only way to drive the RCCL calls on a one-GPU box)")
     return ap.parse_args(argv)
 
 
@@ -454,7 +456,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    if world > 1:
+    if world > 1 or args.force_multi:
         import bench_multi
         result = bench_multi.run(args, sys.modules[__name__])
         if rank == 0:

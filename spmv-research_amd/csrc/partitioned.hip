@@ -201,7 +201,7 @@ step(spmv_mi355x_partitioned * P)
 		if (spmv_mi355x_spmv_device_async(a.loc, a.x_full, a.y, 0, a.comp))
 			return 1;
 	}
-	if (P->nparts > 1 && exchange_x(P))
+	if ((P->nparts > 1 || P->exchange == 1) && exchange_x(P))
 		return 1;
 	for (Part & a : P->parts)
 	{
@@ -379,7 +379,7 @@ spmv_mi355x_create_partitioned(spmv_mi355x_partitioned ** out, int nparts, const
 		P->mem_footprint += spmv_mi355x_mem_footprint(a.loc) + spmv_mi355x_mem_footprint(a.rem);
 	}
 	// ---- exchange back end
-	if (!rc && nparts > 1)
+	if (!rc && (nparts > 1 || exchange == 1))          // one part with the RCCL back end forced: the library calls, on one device
 	{
 		if (exchange != 2 && distinct && rccl().ok)
 		{

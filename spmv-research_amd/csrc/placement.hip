@@ -195,30 +195,33 @@ tune_placement(spmv_mi355x_matrix * A)
 	std::vector<Slot *> movable;
 	size_t site_bytes = 0;
 	bool anchored = false;
+	static const size_t cap = getenv("SPMV_MI355X_PLACEMENT_CAP_GIB") ? (size_t) atol(getenv("SPMV_MI355X_PLACEMENT_CAP_GIB")) << 30 : (size_t) 1 << 30;
 	for (Slot & sl : all)
 	{
-		if (sl.size == largest && !anchored && sl.p != &A->d_y && sl.p != &A->d_x)
+		if (sl.size == largest && !anchored && sl.p != &A->d_y && sl.p != &A->d_x && sl.size > cap)
 		{
 			anchored = true;                        // the big stream everything else is placed against
 			continue;
 		}
-		if (sl.size >= ((size_t) 16 << 20) && sl.size <= ((size_t) 1 << 30))
+		if (sl.size >= ((size_t) 16 << 20) && sl.size <= cap)
 		{
 			sl.off = site_bytes;
 			site_bytes += (sl.size + ((size_t) 2 << 20) - 1) / ((size_t) 2 << 20) * ((size_t) 2 << 20);
 			movable.push_back(&sl);
 		}
 	}
-	if (!anchored || movable.empty())
+	if (movable.empty())
 		return 0;
+	std::stable_sort(movable.begin(), movable.end(), [&](const Slot * a, const Slot * b) { return (a->size == largest) > (b->size == largest); });
+	const size_t ballast_bytes = site_bytes + ((size_t) 1 << 30) < BALLAST_STEP ? BALLAST_STEP - site_bytes : (size_t) 1 << 30;
 	std::vector<void *> ballast, sites;
 	for (int s = 0; s < 10; s++)
 	{
 		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < BALLAST_STEP + site_bytes + KEEP_FREE)
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < ballast_bytes + site_bytes + KEEP_FREE)
 			break;
 		void * b = nullptr, * site = nullptr;
-		if (hipMalloc(&b, BALLAST_STEP) != hipSuccess)
+		if (hipMalloc(&b, ballast_bytes) != hipSuccess)
 		{
 			(void) hipGetLastError();
 			break;

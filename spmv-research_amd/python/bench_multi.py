@@ -209,7 +209,7 @@ class RowsVariant:
                 ok = False
                 self.exchange_info["p2p_error"] = repr(e)[:200]
             if _all_agree(dist, torch, ok):
-                self.exchange_info["p2p_recv_fraction_of_allgather"] = round(self.exch.recv_elems / float((c.world - 1) * self.padded), 4)
+                self.exchange_info["p2p_recv_fraction_of_allgather"] = round(self.exch.recv_elems / float(max(c.world - 1, 1) * self.padded), 4)
                 if self.exchange == "p2p":
                     self.use_p2p = True
                 else:

@@ -15,10 +15,10 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(world, extra, port):
+def _run(world, extra, port, backend="gloo"):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "4",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", backend, "--steps", "4",
            "--warmup", "2"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -71,3 +71,23 @@ def test_multirank_bench_line(world, extra, kind, variants):
         c = V["graph+halo"]["partition"]["considered_max_remote_x_entries"]
         assert c["graph"] < c["rows"]
     assert j["setup_s"]["max_host_rss_gib_over_ranks"] > 0
+
+
+RCCL_CASES = [
+    (["--scale", "0.02"], "rows+allgather"),                                       # in-place all_gather_into_tensor (+ the p2p exchange it is compared with)
+    (["--scale", "0.02", "--partition", "graph"], "graph+halo"),                   # all_to_all_single of the halo lists and of the packed halo
+    (["--scale", "0.02", "--partition", "graph", "--halo", "p2p"], "graph+halo"),  # batched isend / irecv
+]
+
+
+@pytest.mark.parametrize("extra,must_have", RCCL_CASES, ids=["rows", "graph-alltoall", "graph-p2p"])
+def test_rccl_calls_with_one_rank(extra, must_have):
+    """The N > 1 code path on the real backend (nccl = RCCL) with WORLD_SIZE = 1 — all a one-GPU box allows: process-group
+    initialisation, the in-place all_gather_into_tensor of the row-block scheme, all_to_all_single / batched isend-irecv of the
+    packed halo (empty with one rank), the timing all_reduce. Exchange volumes are trivially zero; what is under test is that
+    every RCCL call bench.py makes is accepted by the library."""
+    j = _run(1, ["--force-multi"] + extra, 29950, backend="nccl")
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["variant"] in j["variants"]
+    assert must_have in j["variants"]
+    for v in j["variants"].values():
+        assert v["check_max_err_over_abs_row"] <= 1e-12

@@ -126,3 +126,21 @@ def test_driver_artificial_matrix_mode(tmp_path):
     assert len(f) == 28 and f[1:4] == ["normal", "random", "14"] and f[4:6] == ["20000", "20000"] and f[23].startswith("MI355X_CSR_VECTOR")
     assert abs(float(f[10]) - 12.5) < 0.2 and float(f[25]) > 0                      # avg_nnz_per_row as asked, gflops measured
     assert "Test failed" not in r.stdout + r.stderr and "time generate artificial matrix" in r.stdout
+
+
+def test_rccl_back_end_with_one_part(eng, oracle):
+    """exchange = 1 forced on ONE part: librccl is dlopen'ed, ncclCommInitAll(1 device) and the grouped in-place ncclAllGather
+    of the one slice run on the real library — all a one-GPU box allows of the RCCL back end (csrc/partitioned.hip)."""
+    import spmv_host as H
+    A = H.gen_kkt(12)
+    rp, ci, a, m, n = A["row_ptr"], A["col_idx"], A["values"], A["m"], A["n"]
+    x = np.random.default_rng(9).uniform(-1, 1, n)
+    P = eng.PartitionedMatrix(rp, ci, a, m, n, 1, "sell_c_sigma", np.float64, devices=[0], exchange=1)
+    assert "RCCL" in P.exchange
+    y = P.spmv(x)
+    absrow = oracle.csr_spmv(rp, ci, np.abs(a), np.abs(x))
+    assert np.all(np.abs(y - oracle.csr_spmv(rp, ci, a, x)) <= 1e-12 * absrow + 1e-300)
+    assert P.time(5) > 0
+    y2 = P.spmv(2 * x)
+    assert np.all(np.abs(y2 - 2 * y) <= 4e-12 * absrow + 1e-300)
+    P.close()

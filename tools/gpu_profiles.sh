@@ -7,7 +7,11 @@ set -o pipefail
 ROUND=${1:-r02}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# PMC passes first: the bench lines that follow attach traffic records only when they were collected on the same kernel sources
+if [ -z "$ONLY_BENCH" ]; then
+  bash tools/collect_traffic.sh "nlpkkt240:sell_c_sigma:f64 nlpkkt240:csr_stream:f64 cant:sell_c_sigma:f64 cant:csr_vector:f64 cant:csr_stream:f64 scircuit:csr_vector:f64 scircuit:csr_vector:f64:lanes_per_row=64,rows_per_group=2 pwtk:sell_c_sigma:f32 pwtk:csr_stream:f32 soc-LiveJournal1:coo:f64:col_blocks=-1 soc-LiveJournal1:csr_merge:f64 soc-LiveJournal1:csr_merge:f64:col_blocks=-2"
+  python tools/collect_traffic.py gpurun_out/traffic gpurun_out/traffic_${ROUND}.json
+  cp gpurun_out/traffic_${ROUND}.json profiles/traffic_${ROUND}.json
+fi
 timeout -k 10 900 python bench.py > gpurun_out/${ROUND}_bench_default.json 2> gpurun_out/${ROUND}_bench_default.err; echo "bench rc=$?"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${ROUND}_prof_bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/${ROUND}_bench_profiled.json 2> gpurun_out/${ROUND}_bench_profiled.err; echo "profiled bench rc=$?"
-bash tools/collect_traffic.sh "nlpkkt240:sell_c_sigma:f64 nlpkkt240:csr_stream:f64 cant:sell_c_sigma:f64 cant:csr_vector:f64 cant:csr_stream:f64 scircuit:csr_vector:f64 scircuit:csr_vector:f64:lanes_per_row=64,rows_per_group=2 pwtk:sell_c_sigma:f32 pwtk:csr_stream:f32 soc-LiveJournal1:coo:f64:col_blocks=-1 soc-LiveJournal1:csr_merge:f64 soc-LiveJournal1:csr_merge:f64:col_blocks=-2"
-python tools/collect_traffic.py gpurun_out/traffic gpurun_out/traffic_${ROUND}.json
