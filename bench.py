@@ -102,6 +102,9 @@ def parse(argv=None):
     ap.add_argument("--variants", default="auto", choices=["auto", "both", "one"],
                     help="N>1: 'both' = time the north-star scheme (row blocks + allgather(x)) AND the auto choice in one run and "
                          "report both under \"variants\" (value = the faster); auto = both unless --partition/--exchange is given")
+    ap.add_argument("--host-chunk-nnz", type=int, default=48_000_000,
+                    help="N>1: a rank generates and converts its rows in pieces of at most this many non-zeros (one handle per piece), so its "
+                         "host copy of the matrix never exceeds a piece; 0 = the whole block at once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")

@@ -89,6 +89,11 @@ int  spmv_host_gen_kkt_rows(long N, unsigned long seed, const int32_t * rows, lo
  * col_idx[capacity], values[capacity] or NULL for the structure alone: no second copy of a rank's block is ever made. */
 int  spmv_host_gen_kkt_rows_into(long N, unsigned long seed, const int32_t * rows, long row_begin, long count, int32_t * row_ptr,
 		int32_t * col_idx, double * values, long capacity);
+/* The same rows with a COLUMN FILTER applied while they are generated: keep_inside = 1 keeps the columns in [col_lo, col_hi), 0 the
+ * others — the local-column / remote-column halves of a rank's row block (the overlap scheme of SURVEY §8e) without ever holding
+ * the unfiltered block on the host. col_idx == NULL: only row_ptr (the filtered prefix) is computed, to size the arrays. */
+int  spmv_host_gen_kkt_rows_filtered(long N, unsigned long seed, const int32_t * rows, long row_begin, long count, long col_lo, long col_hi,
+		int keep_inside, int32_t * row_ptr, int32_t * col_idx, double * values, long capacity);
 /* In place: in a fraction `frac` of the rows every off-diagonal column moves by a random offset in [-span, span] (rows stay
  * sorted and duplicate-free). Breaks the translation invariance of a generated matrix: bench.py --jitter measures how much
  * of the compressed-index SELL format's advantage rests on it. */

@@ -36,6 +36,8 @@ int gen_kkt(long N, unsigned long seed, spmv_host_csr * out);
 int gen_kkt_row_ptr(long N, int32_t * row_ptr, long * m_out, long * nnz_out);
 int gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out);
 int gen_kkt_rows(long N, unsigned long seed, const int32_t * rows, long count, spmv_host_csr * out);
+int gen_kkt_rows_filtered(long N, unsigned long seed, const int32_t * rows, long r0, long count, long col_lo, long col_hi, int keep_inside,
+		int32_t * row_ptr, int32_t * col_idx, double * values, long capacity);
 int gen_kkt_rows_into(long N, unsigned long seed, const int32_t * rows, long r0, long count, int32_t * row_ptr, int32_t * col_idx, double * values,
 		long capacity);
 int jitter_columns(long m, long n, const int32_t * row_ptr, int32_t * col_idx, double * values, double frac, long span, unsigned long seed);

@@ -155,6 +155,13 @@ spmv_host_gen_kkt_rows(long N, unsigned long seed, const int32_t * rows, long co
 }
 
 int
+spmv_host_gen_kkt_rows_filtered(long N, unsigned long seed, const int32_t * rows, long row_begin, long count, long col_lo, long col_hi,
+		int keep_inside, int32_t * row_ptr, int32_t * col_idx, double * values, long capacity)
+{
+	return gen_kkt_rows_filtered(N, seed, rows, row_begin, count, col_lo, col_hi, keep_inside ? 1 : 0, row_ptr, col_idx, values, capacity);
+}
+
+int
 spmv_host_gen_kkt_rows_into(long N, unsigned long seed, const int32_t * rows, long row_begin, long count, int32_t * row_ptr, int32_t * col_idx,
 		double * values, long capacity)
 {

@@ -341,6 +341,79 @@ gen_kkt_rows_into(long N, unsigned long seed, const int32_t * rows, long r0, lon
 	return 0;
 }
 
+// Rows with a COLUMN FILTER applied while they are generated: keep_inside = 1 keeps columns in [col_lo, col_hi), 0 keeps the others —
+// the local-column / remote-column halves of a rank's row block (SURVEY §8e overlap scheme) without ever holding the unfiltered
+// block. col_idx == NULL: only row_ptr (the filtered lengths) is computed, so that the caller can size its arrays exactly.
+int
+gen_kkt_rows_filtered(long N, unsigned long seed, const int32_t * rows, long r0, long count, long col_lo, long col_hi, int keep_inside,
+		int32_t * row_ptr, int32_t * col_idx, double * values, long capacity)
+{
+	Grid G;
+	if (make_grid(N, G))
+		return 1;
+	const long m = G.n1 + G.n2;
+	auto row_of = [&](long li) { return rows ? (long) rows[li] : r0 + li; };
+	long bad = -1;
+	row_ptr[0] = 0;
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 8192) reduction(max : bad)
+	for (long li = 0; li < count; li++)
+	{
+		const long r = row_of(li);
+		if (r < 0 || r >= m)
+		{
+			bad = std::max(bad, li);
+			row_ptr[li + 1] = 0;
+			continue;
+		}
+		int32_t tmp[64];
+		const int k = kkt_row_cols(G, r, tmp);
+		int kept = 0;
+		for (int q = 0; q < k; q++)
+			kept += ((tmp[q] >= col_lo && tmp[q] < col_hi) ? 1 : 0) == keep_inside;
+		row_ptr[li + 1] = kept;
+	}
+	if (bad >= 0)
+	{
+		set_error("KKT row list: entry %ld is outside [0,%ld)", bad, m);
+		return 1;
+	}
+	long acc = 0;
+	for (long li = 0; li < count; li++)
+	{
+		acc += row_ptr[li + 1];
+		if (acc >= 0x7fffffffL)
+		{
+			set_error("KKT rows: more than 2^31 non-zeros");
+			return 1;
+		}
+		row_ptr[li + 1] = (int32_t) acc;
+	}
+	if (!col_idx)
+		return 0;
+	if (acc > capacity)
+	{
+		set_error("KKT rows: %ld non-zeros exceed the caller's arrays (%ld)", acc, capacity);
+		return 1;
+	}
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 8192)
+	for (long li = 0; li < count; li++)
+	{
+		const long i = row_of(li);
+		int32_t tmp[64];
+		const int k = kkt_row_cols(G, i, tmp);
+		long o = row_ptr[li];
+		for (int q = 0; q < k; q++)
+			if (((tmp[q] >= col_lo && tmp[q] < col_hi) ? 1 : 0) == keep_inside)
+			{
+				col_idx[o] = tmp[q];
+				if (values)
+					values[o] = sym_value(seed, i, tmp[q]);
+				o++;
+			}
+	}
+	return 0;
+}
+
 int
 gen_kkt_block(long N, unsigned long seed, long r0, long r1, spmv_host_csr * out)
 {

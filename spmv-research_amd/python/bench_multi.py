@@ -23,6 +23,39 @@ import time
 import numpy as np
 
 
+def _rss(tag, rank=None):
+    """Peak host memory so far (SPMV_BENCH_VERBOSE): where a rank's high-water mark comes from."""
+    if os.environ.get("SPMV_BENCH_VERBOSE"):
+        import resource
+        print(f"[bench] rank {os.environ.get('RANK', '0')} peak RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / (1 << 20):.2f} GiB after {tag}",
+              file=sys.stderr, flush=True)
+
+
+class PeakRSS:
+    """Peak resident set of THIS process over a section: the kernel's high-water mark (VmHWM) can be reset by the process itself
+    (/proc/self/clear_refs <- 5), so a section's own peak can be read apart from what came before it (the gloo rehearsals stage
+    every collective through host buffers, which would otherwise hide what building the matrix costs)."""
+
+    def __init__(self):
+        self.ok = True
+        try:
+            with open("/proc/self/clear_refs", "w") as f:
+                f.write("5")
+        except Exception:
+            self.ok = False
+
+    def gib(self):
+        try:
+            with open("/proc/self/status") as f:
+                for line in f:
+                    if line.startswith("VmHWM:"):
+                        return int(line.split()[1]) / (1 << 20)
+        except Exception:
+            pass
+        import resource
+        return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / (1 << 20)
+
+
 class VariantUnavailable(Exception):
     """Raised on EVERY rank together (the decision went through an all-reduce): this variant's exchange did not validate on this
     backend; the run goes on with the other variant."""
@@ -54,6 +87,20 @@ class Source:
         return dict(m=r1 - r0, n=self.n, nnz=e - s, row_ptr=(A["row_ptr"][r0:r1 + 1] - s).astype(np.int32),
                     col_idx=np.ascontiguousarray(A["col_idx"][s:e]).copy(), values=np.ascontiguousarray(A["values"][s:e]).copy())
 
+    def block_filtered(self, r0, r1, col_lo, col_hi, keep_inside):
+        """Rows [r0, r1) with only the columns inside / outside [col_lo, col_hi) (original numbering)."""
+        if self.kkt:
+            return self.H.gen_kkt_rows_filtered(self.N, col_lo, col_hi, keep_inside, r0=r0, count=r1 - r0)
+        A = self.A
+        s, e = int(A["row_ptr"][r0]), int(A["row_ptr"][r1])
+        ci, va = A["col_idx"][s:e], A["values"][s:e]
+        keep = ((ci >= col_lo) & (ci < col_hi)) == bool(keep_inside)
+        row_of = np.repeat(np.arange(r1 - r0), np.diff(A["row_ptr"][r0:r1 + 1].astype(np.int64)))
+        rp = np.zeros(r1 - r0 + 1, np.int64)
+        np.cumsum(np.bincount(row_of[keep], minlength=r1 - r0), out=rp[1:])
+        return dict(m=r1 - r0, n=self.n, nnz=int(rp[-1]), row_ptr=rp.astype(np.int32), col_idx=np.ascontiguousarray(ci[keep]),
+                    values=np.ascontiguousarray(va[keep]))
+
     def rows(self, rows, values=True):
         """An ascending list of rows as a CSR with original column numbers; values=False: the structure alone."""
         if self.kkt:
@@ -79,6 +126,26 @@ class Source:
         if self.kkt:
             return self.H.kkt_partition_volume(self.N, owner, world)
         return self.H.partition_volume(self.A["row_ptr"], self.A["col_idx"], owner, world)
+
+
+def _chunks(lens, max_nnz):
+    """(i0, i1) index ranges over a list of rows with lengths `lens`, each of at most max_nnz non-zeros (at least one row);
+    max_nnz <= 0: one range. A rank builds its handles piece by piece so that its host copy of the matrix never exceeds a piece."""
+    n = len(lens)
+    if n == 0:
+        return []
+    if max_nnz <= 0:
+        return [(0, n)]
+    pre = np.concatenate([[0], np.cumsum(np.asarray(lens, np.int64))])
+    pieces = max(1, int(-(-int(pre[-1]) // max_nnz)))
+    cuts = np.unique(np.concatenate([[0], np.searchsorted(pre, np.arange(1, pieces) * (pre[-1] / pieces)), [n]]))
+    return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
+def _merge_samples(sa, sb):
+    """Samples of the same rows taken from the local-column and the remote-column half of a block: one sample per row."""
+    assert len(sa) == len(sb)
+    return [(ya, np.concatenate([ca, cb]), np.concatenate([va, vb])) for (ya, ca, va), (yb, cb, vb) in zip(sa, sb) if ya == yb]
 
 
 def _bcast_array(dist, torch, arr, src, device):
@@ -135,21 +202,40 @@ class RowsVariant:
         D, E, torch, dist = c.D, c.E, c.torch, c.dist
         self.offsets = D.row_partition(c.src.row_ptr, c.world)
         self.r0, self.r1 = int(self.offsets[c.rank]), int(self.offsets[c.rank + 1])
-        t0 = time.time()
-        self.blk = c.src.block(self.r0, self.r1)
         self.padded = D.padded_len(self.offsets)
         self.n_x = self.padded * c.world
-        D.to_padded_columns(self.blk["col_idx"], self.offsets, self.padded)   # x lives as `world` slices padded to a common length
-        self.t_gen = time.time() - t0
-        t0 = time.time()
-        b, lm = self.blk, self.blk["m"]
-        if c.args.overlap:
-            c0, c1 = c.rank * self.padded, c.rank * self.padded + (self.r1 - self.r0)
-            self.mats = [E.Matrix(b["row_ptr"], b["col_idx"], b["values"], lm, self.n_x, c.fmt, c.np_dtype, col_begin=c0, col_end=c1,
-                                  col_filter_mode=mode, **c.opts) for mode in (1, 2)]
-        else:
-            self.mats = [E.Matrix(b["row_ptr"], b["col_idx"], b["values"], lm, self.n_x, c.fmt, c.np_dtype, **c.opts)]
-        self.t_conv = time.time() - t0
+        lm = self.r1 - self.r0
+        # The block is generated and converted PIECE BY PIECE (--host-chunk-nnz), and with the overlap scheme its local-column and
+        # remote-column halves are generated separately (the generator filters): the host never holds more than one half of one
+        # piece. Every piece becomes its own handle writing its own rows of y.
+        peak = PeakRSS()
+        self.launches, self.samples = [], []              # (local-column handle, remote-column handle or None, first row of y)
+        touched = np.zeros(self.n_x, bool)                # padded columns the block reads (for the trimmed exchange)
+        self.t_gen = self.t_conv = 0.0
+        lens = np.diff(np.asarray(c.src.row_ptr[self.r0:self.r1 + 1], np.int64))
+        pieces = _chunks(lens, c.args.host_chunk_nnz)
+        for k, (i0, i1) in enumerate(pieces):
+            a0, a1 = self.r0 + i0, self.r0 + i1
+            halves = []
+            for keep in ((1, 0) if c.args.overlap else (None,)):
+                t0 = time.time()
+                blk = c.src.block(a0, a1) if keep is None else c.src.block_filtered(a0, a1, self.r0, self.r1, keep)
+                D.to_padded_columns(blk["col_idx"], self.offsets, self.padded)   # x lives as `world` slices padded to a common length
+                if keep != 1:
+                    touched[blk["col_idx"]] = True
+                self.t_gen += time.time() - t0
+                smp = _take_samples(blk, i0, self.col_map, max(2000 // len(pieces), 50), seed=1 + k)
+                t0 = time.time()
+                halves.append((E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], i1 - i0, self.n_x, c.fmt, c.np_dtype, **c.opts), smp))
+                self.t_conv += time.time() - t0
+                del blk
+            self.samples += halves[0][1] if len(halves) == 1 else _merge_samples(halves[0][1], halves[1][1])
+            self.launches.append((halves[0][0], halves[1][0] if len(halves) > 1 else None, i0))
+        self.mats = [M for l in self.launches for M in l[:2] if M is not None]
+        _rss("rows: handles built")
+        self.build_peak_rss_gib = peak.gib()
+        self.ranges = D.subranges_of_touched(touched, self.padded, c.world)
+        del touched
         self.x_full = torch.zeros(self.n_x, dtype=c.t_dtype, device="cuda")
         self.x_loc = self.x_full[c.rank * self.padded:(c.rank + 1) * self.padded]       # in-place allgather: own slice lives inside x_full
         self._fill_own()
@@ -162,9 +248,7 @@ class RowsVariant:
         self.info = {"kind": "rows"}
         self.exchange_info = {"chosen": "allgather"}
         self.lm = lm
-        self.samples = _take_samples(b, 0, self.col_map, 2000)
         self._validate()
-        self.blk = None                                   # the handles hold the matrix now: the host copy of the block goes
 
     def _fill_own(self):
         self.x_loc[:self.r1 - self.r0].copy_(self.ctx.torch.from_numpy(self.ctx.x_host[self.r0:self.r1]))
@@ -198,7 +282,7 @@ class RowsVariant:
             ok = True
             try:
                 self.exch = D.TrimmedExchange(dist, self.x_full, self.padded, c.rank, c.world,
-                                              ranges=D.needed_subranges(self.blk["col_idx"], self.padded, c.world))
+                                              ranges=self.ranges)
                 self.x_full.zero_()
                 self._fill_own()
                 for r in self.exch.start():
@@ -234,24 +318,30 @@ class RowsVariant:
     def step(self):
         c = self.ctx
         reqs = self._exchange()
+        xp, yp, vb = self.x_full.data_ptr(), self.y.data_ptr(), c.vbytes
         if c.args.overlap:
-            self.mats[0].spmv_device(self.x_full.data_ptr(), self.y.data_ptr(), 0, c.sp)      # local columns: only the own slice of x
+            for loc, _rem, first in self.launches:
+                loc.spmv_device(xp, yp + first * vb, 0, c.sp)         # local columns: only the own slice of x
             for r in reqs:
                 r.wait()
-            self.mats[1].spmv_device(self.x_full.data_ptr(), self.y.data_ptr(), 1, c.sp)      # remote columns, y += ...
+            for _loc, rem, first in self.launches:
+                rem.spmv_device(xp, yp + first * vb, 1, c.sp)         # remote columns, y += ...
         else:
             for r in reqs:
                 r.wait()
-            self.mats[0].spmv_device(self.x_full.data_ptr(), self.y.data_ptr(), 0, c.sp)
+            for M, _none, first in self.launches:
+                M.spmv_device(xp, yp + first * vb, 0, c.sp)
 
     def comm_only(self):
         for r in self._exchange():
             r.wait()
 
     def kernels_only(self):
-        self.mats[0].spmv_device(self.x_full.data_ptr(), self.y.data_ptr(), 0, self.ctx.sp)
-        if self.ctx.args.overlap:
-            self.mats[1].spmv_device(self.x_full.data_ptr(), self.y.data_ptr(), 1, self.ctx.sp)
+        xp, yp, vb = self.x_full.data_ptr(), self.y.data_ptr(), self.ctx.vbytes
+        for loc, rem, first in self.launches:
+            loc.spmv_device(xp, yp + first * vb, 0, self.ctx.sp)
+            if rem is not None:
+                rem.spmv_device(xp, yp + first * vb, 1, self.ctx.sp)
 
     def col_map(self, cols):
         p = cols // self.padded
@@ -265,8 +355,8 @@ class RowsVariant:
     def close(self):
         for M in self.mats:
             M.close()
-        self.mats = []
-        self.x_full = self.x_loc = self.x_send = self.y = self.blk = self.exch = None
+        self.mats, self.launches = [], []
+        self.x_full = self.x_loc = self.x_send = self.y = self.exch = None
         if getattr(self, "y_vec", None) is not None:
             self.y_vec.free()
             self.y_vec = None
@@ -282,16 +372,27 @@ class GraphVariant:
         n = c.src.n
         t0 = time.time()
         mine = np.flatnonzero(owner == c.rank).astype(np.int32)           # the rank's rows, ascending original order
-        # pass 1 on the STRUCTURE alone: which rows read a peer's x (boundary), which x entries arrive from whom
-        st = c.src.rows(mine, values=False)
-        lens = np.diff(st["row_ptr"].astype(np.int64))
-        remote = owner[st["col_idx"]] != c.rank
+        # pass 1 on the STRUCTURE alone, piece by piece: which rows read a peer's x (boundary), which x entries arrive from whom
+        my_lens = (np.asarray(c.src.row_ptr, np.int64)[mine.astype(np.int64) + 1] - np.asarray(c.src.row_ptr, np.int64)[mine])
         per_row = np.zeros(len(mine), np.int64)
-        nz = np.flatnonzero(lens > 0)
-        if len(nz):
-            per_row[nz] = np.add.reduceat(remote.astype(np.int64), st["row_ptr"][:-1][nz].astype(np.int64))
-        recv = D.recv_lists_from_block(st, owner, c.rank, c.world)
-        del st, remote
+        need = np.zeros(n, bool)                                          # x entries of peers that the rank's rows read
+        _rss("graph: start")
+        peak = PeakRSS()
+        for i0, i1 in _chunks(my_lens, min(c.args.host_chunk_nnz, 16_000_000) if c.args.host_chunk_nnz > 0 else 0):
+            st = c.src.rows(mine[i0:i1], values=False)
+            _rss("graph: structure piece generated")
+            remote = owner[st["col_idx"]] != c.rank
+            _rss("graph: structure piece owner lookup")
+            nz = np.flatnonzero(my_lens[i0:i1] > 0)
+            if len(nz):
+                per_row[i0 + nz] = np.add.reduceat(remote, st["row_ptr"][:-1][nz].astype(np.int64), dtype=np.int64)
+            _rss("graph: structure piece reduceat")
+            need[st["col_idx"][remote]] = True
+            del st, remote
+        _rss("graph: structure pass")
+        self.build_peak_rss_gib = peak.gib()
+        recv = [np.flatnonzero(need & (owner == q)).astype(np.int32) if q != c.rank else np.zeros(0, np.int32) for q in range(c.world)]
+        del need
         is_b = per_row > 0
         rows_int, rows_bnd = mine[~is_b], mine[is_b]                      # both ascending; every row whole
         split = int(len(rows_int))
@@ -336,14 +437,20 @@ class GraphVariant:
         # (handle, first row of y it writes, phase: 0 = while the halo is in flight, 1 = after it has arrived); a block's host copy
         # lives only while its handle is being built
         parts = ((rows_int, 0, 0), (rows_bnd, split, 1)) if c.args.overlap else ((self.rows, 0, 1),)
+        peak = PeakRSS()                                     # apart from the exchange validation above
         for k, (rws, first, phase) in enumerate(parts):
             if len(rws) == 0:
                 continue
-            b = c.src.rows(rws)
-            self.samples += _take_samples(b, first, None, 1000, seed=1 + k)
-            self.launches.append((E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n, c.fmt, c.np_dtype, **c.opts), first, phase))
-            del b
+            lens = np.asarray(c.src.row_ptr, np.int64)[rws.astype(np.int64) + 1] - np.asarray(c.src.row_ptr, np.int64)[rws]
+            pieces = _chunks(lens, c.args.host_chunk_nnz)
+            for j, (i0, i1) in enumerate(pieces):                 # piece by piece: the host holds one piece of the block at a time
+                b = c.src.rows(rws[i0:i1])
+                self.samples += _take_samples(b, first + i0, None, max(1000 // len(pieces), 50), seed=1 + 16 * k + j)
+                self.launches.append((E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n, c.fmt, c.np_dtype, **c.opts), first + i0, phase))
+                del b
         self.mats = [l[0] for l in self.launches]
+        _rss("graph: handles built")
+        self.build_peak_rss_gib = max(self.build_peak_rss_gib, peak.gib())
         self.t_conv = time.time() - t0
         self.y_vec = self.mats[0].output_vector(self.lm + 64)   # placed by the engine relative to the first block's arrays
         self.y = self.y_vec.torch()
@@ -466,6 +573,7 @@ def run(args, B):
     t0 = time.time()
     c.src = Source(H, B, workload, args.scale)
     t_src = time.time() - t0
+    _rss("imports + process group + source")
     src = c.src
     if src.m != src.n:
         raise SystemExit("row-partitioned SpMV with an x exchange assumes a square matrix (x slices follow the row blocks)")
@@ -492,6 +600,7 @@ def run(args, B):
         if args.partition == "auto" and int(volume.max()) >= int(rows_vol.max()):
             want_graph = False                                       # banded / FEM matrices: contiguous row blocks read no more
     t_part = time.time() - t0
+    _rss("partition")
     plan = []
     if one:
         plan.append("graph+halo" if want_graph else "rows")
@@ -516,7 +625,8 @@ def run(args, B):
         v.info["considered_max_remote_x_entries"] = considered
         r = _measure(B, v, c, args.steps, args.warmup)
         r.update(parallelism=v.describe(), partition=v.info, exchange=v.exchange_info, setup_s=round(time.time() - t0, 2),
-                 generate_s=round(v.t_gen, 2), convert_s=round(v.t_conv, 2))
+                 generate_s=round(v.t_gen, 2), convert_s=round(v.t_conv, 2), handles=len(v.mats),
+                 host_peak_rss_gib_building_the_matrix=round(_max_over_ranks(dist, torch, v.build_peak_rss_gib), 2))
         key = "rows+" + v.exchange_info["chosen"] if name == "rows" else name
         if key in results:
             key += " (auto)"
@@ -548,7 +658,8 @@ def run(args, B):
                 "parallelism": q["parallelism"], "format": q["format_name"], "exchange": q["exchange"], "partition": q["partition"],
                 "breakdown_ms": {"exchange_alone": round(q["comm_ms"], 4), "kernels_alone": round(q["kern_ms"], 4),
                                  "overlap_efficiency": round((q["comm_ms"] + q["kern_ms"]) / q["ms_per_step"], 3)},
-                "check_max_err_over_abs_row": q["check"], "setup_s": q["setup_s"]}
+                "check_max_err_over_abs_row": q["check"], "setup_s": q["setup_s"],
+                "host_peak_rss_gib_building_the_matrix": q["host_peak_rss_gib_building_the_matrix"], "handles_per_rank": q["handles"]}
 
     result = {
         "metric": f"GFLOP/s (2*nnz/t, {'fp64' if c.dts == 'f64' else 'fp32'} SpMV y=A*x); achieved HBM GB/s and % of peak in 'roofline'",

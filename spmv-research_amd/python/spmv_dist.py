@@ -308,6 +308,12 @@ def needed_subranges(col_idx_padded, padded, world, max_ranges=MAX_RANGES, min_g
     constraint rows at the very end of the vector): the hull is cut at its largest gaps (>= min_gap entries)."""
     touched = np.zeros(world * padded, bool)
     touched[np.asarray(col_idx_padded, np.int64)] = True
+    return subranges_of_touched(touched, padded, world, max_ranges, min_gap)
+
+
+def subranges_of_touched(touched, padded, world, max_ranges=MAX_RANGES, min_gap=1 << 15):
+    """needed_subranges from the marks themselves (touched[c] = the block reads padded column c): lets a caller that builds its
+    block in pieces accumulate the marks piece by piece."""
     out = np.zeros((world, max_ranges, 2), np.int64)
     for q in range(world):
         pos = np.flatnonzero(touched[q * padded:(q + 1) * padded])

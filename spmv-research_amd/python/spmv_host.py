@@ -15,7 +15,7 @@ SYMBOLS = [
     "spmv_host_gen_kkt_row_ptr", "spmv_host_gen_kkt_block", "spmv_host_remap_columns", "spmv_host_column_ranges",
     "spmv_host_bfs_order", "spmv_host_owners_from_order", "spmv_host_partition_volume", "spmv_host_partition_layout",
     "spmv_host_permuted_block", "spmv_host_halo_lists", "spmv_host_gen_kkt_rows", "spmv_host_jitter_columns",
-    "spmv_host_kkt_bfs_owner", "spmv_host_kkt_partition_volume", "spmv_host_csr_am_stats", "spmv_host_gen_kkt_rows_into",
+    "spmv_host_kkt_bfs_owner", "spmv_host_kkt_partition_volume", "spmv_host_csr_am_stats", "spmv_host_gen_kkt_rows_into", "spmv_host_gen_kkt_rows_filtered",
 ]
 
 
@@ -183,6 +183,23 @@ def gen_kkt_rows_into(N, nnz, rows=None, r0=0, count=None, values=True, seed=14)
     _check(lib().spmv_host_gen_kkt_rows_into(C.c_long(N), C.c_ulong(seed), None if rows is None else _p(rows), C.c_long(r0), C.c_long(count),
                                              _p(rp), _p(ci), None if va is None else _p(va), C.c_long(nnz)))
     assert int(rp[count]) == nnz
+    return dict(m=count, n=kkt_size(N), nnz=nnz, row_ptr=rp, col_idx=ci[:nnz], values=None if va is None else va[:nnz])
+
+
+def gen_kkt_rows_filtered(N, col_lo, col_hi, keep_inside, rows=None, r0=0, count=None, values=True, seed=14):
+    """Rows of the KKT matrix with only the columns inside (keep_inside) / outside [col_lo, col_hi): two calls — the filtered row
+    lengths first, then the entries into arrays of exactly that size."""
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, np.int32)
+        count = len(rows)
+    rp = np.zeros(count + 1, np.int32)
+    args = (C.c_long(N), C.c_ulong(seed), None if rows is None else _p(rows), C.c_long(r0), C.c_long(count), C.c_long(col_lo), C.c_long(col_hi),
+            C.c_int(1 if keep_inside else 0), _p(rp))
+    _check(lib().spmv_host_gen_kkt_rows_filtered(*args, None, None, C.c_long(0)))
+    nnz = int(rp[count])
+    ci = np.empty(max(nnz, 1), np.int32)
+    va = np.empty(max(nnz, 1), np.float64) if values else None
+    _check(lib().spmv_host_gen_kkt_rows_filtered(*args, _p(ci), None if va is None else _p(va), C.c_long(nnz)))
     return dict(m=count, n=kkt_size(N), nnz=nnz, row_ptr=rp, col_idx=ci[:nnz], values=None if va is None else va[:nnz])
 
 

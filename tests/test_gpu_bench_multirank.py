@@ -36,6 +36,10 @@ CASES = [
     (2, ["--scale", "0.01", "--exchange", "allgather", "--partition", "rows"], "rows", ["rows+allgather"]),
     (2, ["--workload", "cant", "--scale", "0.3"], "rows", None),
     (2, ["--workload", "soc-LiveJournal1", "--scale", "0.02"], None, None),
+    # a rank's block generated and converted in several pieces (one handle per piece), both variants, with and without overlap
+    (3, ["--scale", "0.01", "--host-chunk-nnz", "400000"], None, ["rows+allgather", "graph+halo"]),
+    (2, ["--scale", "0.01", "--host-chunk-nnz", "300000", "--overlap", "0"], None, ["rows+allgather", "graph+halo"]),
+    (2, ["--workload", "cant", "--scale", "0.3", "--host-chunk-nnz", "200000"], "rows", None),
 ]
 
 
