@@ -95,6 +95,7 @@ walk(spmv_mi355x_matrix * A, void * first, size_t bytes, Measure measure, void *
 				break;
 			}
 			(void) hipMemset(cand, 0, bytes);
+			(void) hipDeviceSynchronize();
 			const double t = measure(cand);
 			w.tries++;
 			if (t > 0 && t * CONTRAST < w.t_chosen)
@@ -284,6 +285,7 @@ tune_placement(spmv_mi355x_matrix * A)
 	}
 	if (!rc)
 		HIP_TRY(hipMemset(A->d_y, 0, (size_t) (A->m + 64) * A->vbytes));
+	HIP_TRY(hipDeviceSynchronize());
 	for (void * p : ballast)
 		(void) hipFree(p);
 	for (void * p : to_free)
@@ -309,6 +311,7 @@ dev_alloc_output(spmv_mi355x_matrix * A, void ** out, size_t bytes)
 	if (dev_alloc_bytes(out, bytes))
 		return 1;
 	HIP_TRY(hipMemset(*out, 0, std::max<size_t>(bytes, 8)));
+	HIP_TRY(hipDeviceSynchronize());
 	const size_t need = (size_t) (A->m + 64) * A->vbytes;
 	if (setting() == 0 || A->placement_off || bytes < PLACE_MIN_BYTES || bytes < need || !A->d_x)
 		return 0;
@@ -319,6 +322,7 @@ dev_alloc_output(spmv_mi355x_matrix * A, void ** out, size_t bytes)
 	if (chosen != first)
 		HIP_TRY(hipFree(first));
 	HIP_TRY(hipMemset(chosen, 0, bytes));
+	HIP_TRY(hipDeviceSynchronize());
 	*out = chosen;
 	report("an output vector", bytes, w);
 	return 0;

@@ -17,18 +17,18 @@ set_error(const char * fmt, ...)
 	va_end(ap);
 }
 
-// the handle's stream and its own (zeroed) input vector
+// the handle's own (zeroed) input vector. No stream of its own here: callers of the device-pointer entry points bring theirs, and with
+// several processes on one GPU every extra hardware queue costs (4 gloo ranks on one MI355X: halo exchange 2.4 -> 40 ms per step)
 int
 ensure_x(spmv_mi355x_matrix * A)
 {
 	HIP_TRY(hipSetDevice(A->device));
-	if (!A->stream)
-		HIP_TRY(hipStreamCreate(&A->stream));
 	if (!A->d_x)
 	{
 		if (dev_alloc_bytes(&A->d_x, (size_t) std::max<long>(A->n, 1) * A->vbytes))
 			return 1;
 		HIP_TRY(hipMemset(A->d_x, 0, (size_t) std::max<long>(A->n, 1) * A->vbytes));
+		HIP_TRY(hipDeviceSynchronize());                   // the fill runs on the null stream, the handle's stream does not wait for it
 	}
 	return 0;
 }
@@ -317,11 +317,14 @@ ensure_xy(spmv_mi355x_matrix * A)
 {
 	if (ensure_x(A))
 		return 1;
+	if (!A->stream)
+		HIP_TRY(hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking));    // the host-buffer entry points' stream; never serialises with the caller's
 	if (!A->d_y)
 	{
 		if (dev_alloc_bytes(&A->d_y, (size_t) (A->m + 64) * A->vbytes))
 			return 1;
 		HIP_TRY(hipMemset(A->d_y, 0, (size_t) (A->m + 64) * A->vbytes));
+		HIP_TRY(hipDeviceSynchronize());
 		if (tune_placement(A))              // placement.hip: once, now that every array of the handle exists
 			return 1;
 	}
@@ -343,6 +346,7 @@ spmv_mi355x_upload_x(spmv_mi355x_matrix * A, const void * x_host)
 {
 	if (ensure_xy(A))
 		return 1;
+	HIP_TRY(hipDeviceSynchronize());        // the handle's stream is non-blocking: order after whatever the caller queued on other streams
 	HIP_TRY(hipMemcpyAsync(A->d_x, x_host, (size_t) A->n * A->vbytes, hipMemcpyHostToDevice, A->stream));
 	HIP_TRY(hipStreamSynchronize(A->stream));
 	A->cached_x_host = x_host;
@@ -354,6 +358,7 @@ spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host)
 {
 	if (ensure_xy(A))
 		return 1;
+	HIP_TRY(hipDeviceSynchronize());        // the handle's stream is non-blocking: order after whatever the caller queued on other streams
 	HIP_TRY(hipMemcpyAsync(A->d_y, y_host, (size_t) A->m * A->vbytes, hipMemcpyHostToDevice, A->stream));
 	HIP_TRY(hipStreamSynchronize(A->stream));
 	return 0;
@@ -364,6 +369,7 @@ spmv_mi355x_download_y(spmv_mi355x_matrix * A, void * y_host)
 {
 	if (ensure_xy(A))
 		return 1;
+	HIP_TRY(hipDeviceSynchronize());        // the handle's stream is non-blocking: order after whatever the caller queued on other streams
 	HIP_TRY(hipMemcpyAsync(y_host, A->d_y, (size_t) A->m * A->vbytes, hipMemcpyDeviceToHost, A->stream));
 	HIP_TRY(hipStreamSynchronize(A->stream));
 	A->y_downloaded = true;
