@@ -28,7 +28,7 @@ ensure_x(spmv_mi355x_matrix * A)
 		if (dev_alloc_bytes(&A->d_x, (size_t) std::max<long>(A->n, 1) * A->vbytes))
 			return 1;
 		HIP_TRY(hipMemset(A->d_x, 0, (size_t) std::max<long>(A->n, 1) * A->vbytes));
-		HIP_TRY(hipDeviceSynchronize());                   // the fill runs on the null stream, the handle's stream does not wait for it
+		HIP_TRY(hipDeviceSynchronize());
 	}
 	return 0;
 }
@@ -318,7 +318,7 @@ ensure_xy(spmv_mi355x_matrix * A)
 	if (ensure_x(A))
 		return 1;
 	if (!A->stream)
-		HIP_TRY(hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking));    // the host-buffer entry points' stream; never serialises with the caller's
+		HIP_TRY(hipStreamCreate(&A->stream));          // a BLOCKING stream: ordered against the null-stream copies / fills of create() and of placement
 	if (!A->d_y)
 	{
 		if (dev_alloc_bytes(&A->d_y, (size_t) (A->m + 64) * A->vbytes))
@@ -346,7 +346,7 @@ spmv_mi355x_upload_x(spmv_mi355x_matrix * A, const void * x_host)
 {
 	if (ensure_xy(A))
 		return 1;
-	HIP_TRY(hipDeviceSynchronize());        // the handle's stream is non-blocking: order after whatever the caller queued on other streams
+	HIP_TRY(hipDeviceSynchronize());        // a host transfer of the handle's vectors: after whatever the caller queued on its own streams
 	HIP_TRY(hipMemcpyAsync(A->d_x, x_host, (size_t) A->n * A->vbytes, hipMemcpyHostToDevice, A->stream));
 	HIP_TRY(hipStreamSynchronize(A->stream));
 	A->cached_x_host = x_host;
@@ -358,7 +358,7 @@ spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host)
 {
 	if (ensure_xy(A))
 		return 1;
-	HIP_TRY(hipDeviceSynchronize());        // the handle's stream is non-blocking: order after whatever the caller queued on other streams
+	HIP_TRY(hipDeviceSynchronize());        // a host transfer of the handle's vectors: after whatever the caller queued on its own streams
 	HIP_TRY(hipMemcpyAsync(A->d_y, y_host, (size_t) A->m * A->vbytes, hipMemcpyHostToDevice, A->stream));
 	HIP_TRY(hipStreamSynchronize(A->stream));
 	return 0;
@@ -369,7 +369,7 @@ spmv_mi355x_download_y(spmv_mi355x_matrix * A, void * y_host)
 {
 	if (ensure_xy(A))
 		return 1;
-	HIP_TRY(hipDeviceSynchronize());        // the handle's stream is non-blocking: order after whatever the caller queued on other streams
+	HIP_TRY(hipDeviceSynchronize());        // a host transfer of the handle's vectors: after whatever the caller queued on its own streams
 	HIP_TRY(hipMemcpyAsync(y_host, A->d_y, (size_t) A->m * A->vbytes, hipMemcpyDeviceToHost, A->stream));
 	HIP_TRY(hipStreamSynchronize(A->stream));
 	A->y_downloaded = true;

@@ -634,3 +634,24 @@ def test_placement_search_keeps_results(eng):
     np.testing.assert_allclose(v.torch()[:m].cpu().numpy(), ref, rtol=1e-13, atol=1e-13)
     v.free()
     A.close()
+
+
+def test_placement_moves_index_arrays_safely(eng, oracle):
+    """A matrix with scattered columns (4-byte SELL indices: an index array of tens of MiB) and a y above the placement threshold:
+    the pass copies the index array to other sites and times the kernel there — a trial launched before its copy had finished would
+    gather x through garbage columns (that race faulted the GPU once; the copy now runs on the trial's stream)."""
+    m, k = 1_300_000, 12
+    rng = np.random.default_rng(11)
+    ci = np.sort(rng.integers(0, m, (m, k), dtype=np.int64), axis=1)
+    ci += np.arange(k)                                   # strictly increasing inside a row
+    ci = np.minimum(ci, m - 1 - (k - 1 - np.arange(k))).astype(np.int32).reshape(-1)
+    rp = np.arange(0, m * k + 1, k, dtype=np.int32)
+    a = rng.uniform(-1, 1, m * k)
+    A = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma")
+    x = rng.uniform(-1, 1, m)
+    y = A.spmv(x)                                        # first use of the handle's vectors: the placement pass
+    sample = rng.integers(0, m, 3000)
+    ref = np.array([np.dot(a[i * k:(i + 1) * k], x[ci[i * k:(i + 1) * k]]) for i in sample])
+    den = np.array([np.dot(np.abs(a[i * k:(i + 1) * k]), np.abs(x[ci[i * k:(i + 1) * k]])) for i in sample])
+    assert np.all(np.abs(y[sample] - ref) <= 1e-12 * den)
+    A.close()

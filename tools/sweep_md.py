@@ -12,13 +12,14 @@ def main():
     groups = {}
     for r in recs:
         groups.setdefault((r["workload"], r["dtype"]), []).append(r)
-    L = ["# Kernel sweep, round 1 (one MI355X, synthetic twins, device time per launch from HIP events)", "",
+    title = "# Kernel sweep" + (", " + sys.argv[0] if False else "") + " (one MI355X, synthetic twins, device time per launch from HIP events)"
+    L = [title, "",
          "`GB/s` = algorithmic bytes `nnz*(V+4)+(m+1)*4+(n+m)*V` / time; `%` of the 8 TB/s HBM3E spec peak; `mem` = format "
          "footprint / CSR footprint.",
          "Rows with `auto` options are the engine's own choice for that format. cant/scircuit/pwtk (<= 140 MB) are "
          "Infinity-Cache resident after warm-up.", "",
-         "Box-to-box spread of the pool is about 10 % (the same binary on the nlpkkt240 twin: 1485 .. 1680 us): compare rows "
-         "within one table, not across files.", ""]
+         "Round 2 onward every handle runs on its own engine-placed x / y pair (csrc/placement.hip); round-1 tables were taken on "
+         "torch-allocated vectors and carry the ~10 % placement lottery of that round (profiles/r02_placement.md).", ""]
     for (w, dt), rows in groups.items():
         best = min(rows, key=lambda r: r["ms"])
         L += ["", f"## {w} ({dt})", "", "| format | options | us/launch | GFLOP/s | GB/s | % peak | mem |", "|---|---|---|---|---|---|---|"]
