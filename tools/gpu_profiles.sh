@@ -14,4 +14,5 @@ if [ -z "$ONLY_BENCH" ]; then
   cp gpurun_out/traffic_${ROUND}.json profiles/traffic_${ROUND}.json
 fi
 timeout -k 10 900 python bench.py > gpurun_out/${ROUND}_bench_default.json 2> gpurun_out/${ROUND}_bench_default.err; echo "bench rc=$?"
+rm -rf gpurun_out/${ROUND}_prof_bench
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${ROUND}_prof_bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/${ROUND}_bench_profiled.json 2> gpurun_out/${ROUND}_bench_profiled.err; echo "profiled bench rc=$?"
