@@ -279,15 +279,15 @@ def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_war
         M.spmv_device(xp, yp, 0, sp)
     torch.cuda.synchronize()
     # settle: the reference driver warms GPU kernels with 1000 untimed calls (bench_spmv.cpp:287-294). Here: batches of launches for
-    # min_warm_seconds, and then until two batches in a row agree within 0.5 % (at most 1000 launches more) — after the host-to-device
-    # uploads above the first few hundred launches run up to 4 % slower (profiles/r02_placement.md §6)
+    # min_warm_seconds, then at least 500 launches and on until two batches in a row agree within 0.5 % (at most 1500) — after the
+    # host-to-device uploads above the first few hundred launches run up to 6 % slower (profiles/r02_placement.md §6)
     t_w = time.time()
     batch, settle = max(min(steps, 100), 20), []
     while time.time() - t_w < min_warm_seconds:
         M.time_device(xp, yp, batch, sp)
-    while len(settle) * batch < 1000:
+    while len(settle) * batch < 1500:
         settle.append(M.time_device(xp, yp, batch, sp))
-        if len(settle) >= 2 and abs(settle[-1] - settle[-2]) <= 0.005 * settle[-1]:
+        if len(settle) * batch >= 500 and abs(settle[-1] - settle[-2]) <= 0.005 * settle[-1]:
             break
     if os.environ.get("SPMV_BENCH_VERBOSE"):
         print("[bench] settle batches (ms): " + " ".join(f"{v:.4f}" for v in settle), file=sys.stderr)

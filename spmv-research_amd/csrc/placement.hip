@@ -249,6 +249,10 @@ tune_placement(spmv_mi355x_matrix * A)
 	int rc = t_cur < 0;
 	if (t_cur >= 0 && t_cur < 20.0)
 		movable.clear();                   // launch-bound: differences between sites drown in the noise
+	// Two sweeps: what is best for y depends on where x and the index arrays end up (and the other way round)
+	for (int sweep = 0, moved_any = 1; sweep < 2 && moved_any && !rc; sweep++)
+	{
+	moved_any = 0;
 	for (Slot * sl : movable)
 	{
 		if (rc)
@@ -261,6 +265,12 @@ tune_placement(spmv_mi355x_matrix * A)
 		for (size_t s = 0; s < sites.size() && !rc; s++)
 		{
 			void * dst = (char *) sites[s] + sl->off;
+			if (dst == orig)                          // second sweep: the site it already lives at
+			{
+				if (setting() >= 2)
+					fprintf(stderr, " =");
+				continue;
+			}
 			// on the stream the trial launches use, and finished before they start: a kernel that read a half-copied index
 			// array would gather x out of bounds
 			if (hipMemcpyAsync(dst, orig, sl->size, hipMemcpyDeviceToDevice, A->stream) != hipSuccess || hipStreamSynchronize(A->stream) != hipSuccess)
@@ -284,15 +294,24 @@ tune_placement(spmv_mi355x_matrix * A)
 		if (best >= 0 && !rc)
 		{
 			*sl->p = (char *) sites[(size_t) best] + sl->off;
-			used[(size_t) best] = 1;
-			to_free.push_back(orig);
+			bool in_site = false;                  // an array that already lives in a site (second sweep) has no allocation of its own to return
+			for (void * st : sites)
+				in_site = in_site || ((char *) orig >= (char *) st && (char *) orig < (char *) st + site_bytes);
+			if (!in_site)
+				to_free.push_back(orig);
 			t_cur = t_best;
+			moved_any = 1;
 		}
 		else
 			*sl->p = orig;
 		if (setting() >= 2)
 			fprintf(stderr, " -> %s, %.1f us\n", best >= 0 ? "moved" : "stays", t_cur);
 	}
+	}
+	for (size_t s2 = 0; s2 < sites.size(); s2++)       // sites in use at the end
+		for (Slot * sl : movable)
+			if ((char *) *sl->p >= (char *) sites[s2] && (char *) *sl->p < (char *) sites[s2] + site_bytes)
+				used[s2] = 1;
 	if (!rc)
 		HIP_TRY(hipMemset(A->d_y, 0, (size_t) (A->m + 64) * A->vbytes));
 	HIP_TRY(hipDeviceSynchronize());

@@ -522,6 +522,16 @@ def _measure(B, v, c, K, warmup):
     kern_ms = _time_steps(dist, torch, v.kernels_only, 10)
     for _ in range(warmup):
         v.step()
+    # settle, as bench.py does at N = 1 (the reference driver warms GPU kernels with 1000 untimed calls, bench_spmv.cpp:287-294; the first
+    # few hundred launches after the uploads run a few % slower): batches of 20 steps until two agree within 1 %, at least 5 and at most
+    # 15 of them or ~1.5 s. Every decision is taken on all-reduced times, so every rank runs the same number of steps.
+    prev, spent, batches = None, 0.0, 0
+    while batches < 15 and spent < 1500.0:
+        tb = _time_steps(dist, torch, v.step, 20, warm=0)
+        batches, spent = batches + 1, spent + 20 * tb
+        if batches >= 5 and prev is not None and abs(tb - prev) <= 0.01 * tb:
+            break
+        prev = tb
     dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
