@@ -255,7 +255,7 @@ def sampled_row_check(yh, rp, ci, va, x_host, np_dtype, col_map=None, count=2000
     return max_rel, samp
 
 
-def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_warm_seconds=0.0):
+def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_warm_seconds=0.0, idle_after_placement=3.0):
     """Build one handle, run warm-up + `steps` back-to-back launches timed by HIP events on the launch stream, check sampled
     rows. Returns a dict with the measured figures and leaves nothing on the device."""
     np_dtype = np.float64 if dts == "f64" else np.float32
@@ -272,6 +272,11 @@ def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_war
     t0 = time.time()
     M.upload_x(x_host)
     t_place = time.time() - t0
+    if t_place > 0.15 and idle_after_placement > 0:
+        # the placement pass has just returned ~165 GiB of ballast and unused sites to the driver, which clears freed memory in the
+        # background: for the next 2-3 s launches alternate between the normal level and one 5.5 % slower (time series in
+        # profiles/r02_placement.md §6); after a couple of idle seconds they are stable. Not part of any timed region.
+        time.sleep(idle_after_placement)
     xp, yp = M.x_device(), M.y_device()
     M.upload_y(np.ones(m, np_dtype))                               # driver canary (bench_spmv.cpp:606-609)
     sp = torch.cuda.current_stream().cuda_stream
