@@ -277,6 +277,7 @@ def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_war
         # background: for the next 2-3 s launches alternate between the normal level and one 5.5 % slower (time series in
         # profiles/r02_placement.md §6); after a couple of idle seconds they are stable. Not part of any timed region.
         time.sleep(idle_after_placement)
+        t_place += idle_after_placement
     xp, yp = M.x_device(), M.y_device()
     M.upload_y(np.ones(m, np_dtype))                               # driver canary (bench_spmv.cpp:606-609)
     sp = torch.cuda.current_stream().cuda_stream
