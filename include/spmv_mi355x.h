@@ -159,6 +159,9 @@ int  spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host);      /* 
  * kernel on it: when a candidate from deeper in the pool is clearly faster, it replaces the first one. The handle's own y
  * (spmv_mi355x_y_device, used by spmv_mi355x_spmv) is placed this way; output_alloc gives callers of the device-pointer entry
  * points the same for their vectors (bytes >= (rows + 64) values; smaller or < 32 MiB: a plain allocation). Zero-filled.
+ * The search holds up to ~165 GiB of the device's free memory for its duration (ballast between the candidate sites; it never
+ * takes the last 8 GiB and stops early when less is free) and returns everything but the chosen sites; the driver clears returned
+ * memory in the background, which slows the next ~3 s of launches by up to 5 % (bench.py idles through it).
  * SPMV_MI355X_PLACEMENT=0 turns the search off, =2 reports it on stderr. No reference counterpart (the reference's GPU
  * backends hipMalloc their vectors in the constructor, GPU_clean/csr_rocm_vector.cpp:77-86). */
 int  spmv_mi355x_output_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out);
