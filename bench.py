@@ -105,6 +105,9 @@ def parse(argv=None):
     ap.add_argument("--host-chunk-nnz", type=int, default=48_000_000,
                     help="N>1: a rank generates and converts its rows in pieces of at most this many non-zeros (one handle per piece), so its "
                          "host copy of the matrix never exceeds a piece; 0 = the whole block at once")
+    ap.add_argument("--idle-after-placement", type=float, default=3.0,
+                    help="seconds without launches after the engine has placed the vectors: the driver clears the ~165 GiB the search "
+                         "returned in the background, which slows launches by up to 5.5 %% until it is done (profiles/r02_placement.md §6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -485,7 +488,8 @@ def main():
     t_gen = time.time() - t0
     m, n, nnz = A["m"], A["n"], A["nnz"]
     small = nnz < 20_000_000
-    t = time_handle(E, torch, A, fmt, dts, opts, args.steps, args.warmup, min_warm_seconds=0.25 if small else 0.0)
+    t = time_handle(E, torch, A, fmt, dts, opts, args.steps, args.warmup, min_warm_seconds=0.25 if small else 0.0,
+                    idle_after_placement=args.idle_after_placement)
     ms_per_step = t["wall_ms"]                    # barrier + synchronize bracket around exactly K launches
     gflops = 2.0 * nnz / (ms_per_step * 1e-3) / 1e9
     B_alg = t["algorithmic_bytes"]

@@ -520,6 +520,8 @@ def _measure(B, v, c, K, warmup):
     torch, dist = c.torch, c.dist
     comm_ms = _time_steps(dist, torch, v.comm_only, 10)
     kern_ms = _time_steps(dist, torch, v.kernels_only, 10)
+    if v.lm * c.vbytes >= (8 << 20) and c.args.idle_after_placement > 0:
+        time.sleep(c.args.idle_after_placement)      # the placement search has returned its ballast: let the driver finish clearing it (bench.py)
     for _ in range(warmup):
         v.step()
     # settle, as bench.py does at N = 1 (the reference driver warms GPU kernels with 1000 untimed calls, bench_spmv.cpp:287-294; the first
