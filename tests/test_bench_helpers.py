@@ -4,6 +4,8 @@ import importlib.util
 import json
 import os
 
+import numpy as np
+
 from conftest import ROOT
 
 
@@ -83,3 +85,47 @@ def test_default_kernel_per_workload():
     assert b.NAMED_KERNEL["scircuit"][0] == "csr_vector" and b.NAMED_KERNEL["scircuit"][1]["lanes_per_row"] == 64
     assert b.NAMED_KERNEL["pwtk"][0] == "sell_c_sigma" and b.NAMED_KERNEL["soc-LiveJournal1"][0] == "csr_merge"
     assert set(b.SMALL_CONFIGS) | {"nlpkkt240"} == set(b.WORKLOADS) == set(b.NAMED_KERNEL)
+
+
+def test_multi_rank_piece_helpers():
+    """bench_multi builds a rank's handles piece by piece: the pieces cover the rows once, in order, within the nnz budget."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "spmv-research_amd", "python"))
+    import bench_multi as M
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 40, 10_000)
+    for budget in (0, 1, 500, 5_000, 10**9):
+        pieces = M._chunks(lens, budget)
+        assert pieces[0][0] == 0 and pieces[-1][1] == len(lens)
+        assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:])) and all(b > a for a, b in pieces)
+        if budget >= 500:
+            assert max(int(lens[a:b].sum()) for a, b in pieces) <= 1.5 * max(budget, int(lens.sum()) / len(pieces)) + 40
+    assert M._chunks(np.zeros(0, np.int64), 10) == [] and M._chunks(np.array([7]), 3) == [(0, 1)]
+    sa = [(3, np.array([1, 2]), np.array([1.0, 2.0])), (9, np.array([4]), np.array([4.0]))]
+    sb = [(3, np.array([7]), np.array([7.0])), (9, np.zeros(0, np.int64), np.zeros(0))]
+    merged = M._merge_samples(sa, sb)
+    assert [m[0] for m in merged] == [3, 9] and merged[0][1].tolist() == [1, 2, 7] and merged[1][2].tolist() == [4.0]
+    p = M.PeakRSS()
+    assert p.gib() > 0.01
+
+
+def test_filtered_kkt_rows_equal_the_filtered_block():
+    """The generator-side column filter (local / remote halves of a rank's rows) against filtering the generated block."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "spmv-research_amd", "python"))
+    import spmv_host as H
+    N = 10
+    A = H.gen_kkt(N)
+    rp, ci, va, m = A["row_ptr"], A["col_idx"], A["values"], A["m"]
+    for (r0, r1, lo, hi) in ((0, m, 0, m // 3), (200, 1400, 180, 1500), (m - 300, m, 0, 50)):
+        s, e = int(rp[r0]), int(rp[r1])
+        c, v = ci[s:e], va[s:e]
+        rows = np.repeat(np.arange(r1 - r0), np.diff(rp[r0:r1 + 1]))
+        for keep in (1, 0):
+            B = H.gen_kkt_rows_filtered(N, lo, hi, keep, r0=r0, count=r1 - r0)
+            sel = ((c >= lo) & (c < hi)) == bool(keep)
+            assert np.array_equal(np.diff(B["row_ptr"]), np.bincount(rows[sel], minlength=r1 - r0))
+            assert np.array_equal(B["col_idx"], c[sel]) and np.array_equal(B["values"], v[sel])
+    some = np.array([5, 17, 900, 901, m - 1], np.int32)
+    B = H.gen_kkt_rows_filtered(N, 0, 100, 0, rows=some, values=False)
+    assert B["values"] is None and B["m"] == 5 and int(B["row_ptr"][-1]) == B["nnz"] == len(B["col_idx"])
