@@ -105,6 +105,8 @@ def parse(argv=None):
     ap.add_argument("--host-chunk-nnz", type=int, default=48_000_000,
                     help="N>1: a rank generates and converts its rows in pieces of at most this many non-zeros (one handle per piece), so its "
                          "host copy of the matrix never exceeds a piece; 0 = the whole block at once")
+    ap.add_argument("--piece-handles", action="store_true",
+                    help="N>1: one handle per piece instead of one handle converted from the pieces in device memory (tests)")
     ap.add_argument("--idle-after-placement", type=float, default=3.0,
                     help="seconds without launches after the engine has placed the vectors: the driver clears the ~165 GiB the search "
                          "returned in the background, which slows launches by up to 5.5 %% until it is done (profiles/r02_placement.md §6)")

@@ -123,6 +123,23 @@ long   spmv_mi355x_nnz(const spmv_mi355x_matrix * A);                /* local no
 int    spmv_mi355x_precision(const spmv_mi355x_matrix * A);          /* SPMV_MI355X_F64 / SPMV_MI355X_F32           */
 int    spmv_mi355x_device(const spmv_mi355x_matrix * A);             /* HIP device ordinal the handle lives on      */
 
+/* ---- a handle from a CSR that arrives in pieces ---------------------------------------------------------------------- */
+/* spmv_mi355x_create() needs the whole CSR in host memory at once. A caller that generates or reads its rows piece by piece (a rank
+ * of a multi-GPU run: bench.py --gpus N) appends them to a CSR kept in DEVICE memory — every piece is checked like create() checks a
+ * matrix (row_ptr from 0 and monotone, columns in [0, n)) — and gets ONE handle converted on the GPU from the resident CSR; the host
+ * never holds more than a piece. nnz_capacity: an upper bound of the non-zeros to come (device arrays of that size live until
+ * create_from_stream). Pieces are consecutive rows in order; a piece's row_ptr has rows + 1 entries starting at 0.
+ * create_from_stream consumes the stream (also on failure). Formats: SPMV_MI355X_SELL_C_SIGMA with 64-row slices and the delta
+ * layout (what create() picks for large matrices; same arrays, same results); opts fields of other layouts are rejected.
+ * No reference counterpart: csr_to_format() receives complete arrays (spmv_kernel.h:8-29). */
+typedef struct spmv_mi355x_csr_stream spmv_mi355x_csr_stream;
+int  spmv_mi355x_csr_stream_begin(spmv_mi355x_csr_stream ** out, int device /* -1: current */, long m, long n, long nnz_capacity);
+int  spmv_mi355x_csr_stream_append(spmv_mi355x_csr_stream * s, long rows, const int32_t * row_ptr, const int32_t * col_idx,
+		const double * values);
+int  spmv_mi355x_create_from_stream(spmv_mi355x_matrix ** out, spmv_mi355x_csr_stream * s, int format, int precision,
+		const spmv_mi355x_opts * opts);
+int  spmv_mi355x_csr_stream_discard(spmv_mi355x_csr_stream * s);
+
 /* ---- Matrix_Format::spmv(x, y) with HOST buffers --------------------------------------------------------- */
 /* Reference GPU-backend semantics (GPU_clean/csr_rocm_vector.cpp:224-257): x is uploaded when the host
  * pointer is new (or always_copy is set), one launch + device sync, y is downloaded on the first call (or when

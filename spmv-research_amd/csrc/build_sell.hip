@@ -530,4 +530,58 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 	return rc;
 }
 
+
+// SELL-64-sigma-delta from a CSR that is already in device memory (csr_stream.hip: rows appended piece by piece, so that the host never
+// holds the whole matrix): the GPU conversion of build_sell_delta without the upload. Same layout, same names, same results as
+// spmv_mi355x_create() gives for sell_c = 64 with the delta layout converted on the device.
+int
+build_sell_delta_resident(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * d_rp, const int * d_ci, const double * d_va)
+{
+	constexpr int C = 64;
+	const long m = A->m;
+	const char * pf = A->f32 ? "f" : "d";
+	if ((o.sell_c && o.sell_c != C) || o.sell_delta == 2 || o.convert_on == 2 || o.sell_window == 1)
+	{
+		set_error("create_from_stream: only the SELL-64 delta layout converted on the device is built from a device-resident CSR");
+		return 1;
+	}
+	const long sigma = o.sell_sigma ? o.sell_sigma : 16384;
+	if (sigma < C || sigma % C)
+	{
+		set_error("sell_sigma (%ld) must be a positive multiple of sell_c (%d)", sigma, C);
+		return 1;
+	}
+	const long num_slices = (m + C - 1) / C;
+	int S = o.sell_split ? o.sell_split : (num_slices >= 16384 ? 1 : num_slices >= 8192 ? 2 : 4);
+	if (S != 1 && S != 2 && S != 4)
+	{
+		set_error("sell_split must be 1, 2 or 4 (got %d)", S);
+		return 1;
+	}
+	A->sell_c = C;
+	A->sell_sigma = sigma;
+	A->sell_delta = true;
+	A->convert_on_device = true;
+	A->sell_split = S;
+	std::vector<int64_t> val_ptr;
+	int64_t nnz_ext = 0, idx_bytes = 0;
+	void * d_val = nullptr;
+	if (sell_delta_convert_resident(A->f32, m, A->n, A->nnz, sigma, d_rp, d_ci, d_va, &A->d_row_of_sorted, &A->d_sell_desc, &A->d_sell_idx, &d_val,
+			val_ptr, A->sell_mode_slices, &nnz_ext, &idx_bytes))
+		return 1;
+	A->d_val = d_val;
+	A->sell_slices = num_slices;
+	A->sell_nnz_ext = nnz_ext;
+	A->sell_idx_bytes = idx_bytes;
+	const long spt = sell_slices_per_tile() / A->sell_split;
+	A->cfg.map = xcd_map_balanced(val_ptr.data(), num_slices, spt, resolve_remap(A->remap, (num_slices + spt - 1) / spt));
+	A->mem_footprint = (double) (num_slices + 1) * 16 + (double) nnz_ext * A->vbytes + (double) idx_bytes + (double) m * 4;
+	if (A->sell_split > 1)
+		snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELLD_%d_%ld_w%d_%s", C, sigma, A->sell_split, pf);
+	else
+		snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELLD_%d_%ld_%s", C, sigma, pf);
+	snprintf(A->kernel_name, sizeof(A->kernel_name), "sell_delta_kernel");
+	return 0;
+}
+
 }  // namespace spmv

@@ -229,33 +229,22 @@ struct Scratch {
 	}
 };
 
+// The conversion proper, on a CSR that already lives in device memory (rp[m+1] from 0, ci[nnz], va[nnz] as fp64).
 // Outputs (device, owned by the caller on success): row_of_sorted[m], desc[2*(slices+1)], idx[idx_bytes+1024], val[nnz_ext
 // + STREAM_SLACK] of the handle's precision. Host outputs: val_ptr (slices+1, for the tile map), mode counts, sizes.
 int
-sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
-		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
+sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp, const int * ci,
+		const double * va, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
 		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out)
 {
+	(void) nnz;
 	const long num_slices = (m + WAVE - 1) / WAVE;
 	const long num_windows = (m + sigma - 1) / sigma;
 	Scratch tmp;
-	int * rp, * ci, * len, * len_sorted, * ids, * win_off;
-	double * va;
-	if (tmp.get(&rp, (size_t) (m + 1) * 4) || tmp.get(&ci, (size_t) nnz * 4) || tmp.get(&va, (size_t) nnz * 8) ||
-	    tmp.get(&len, (size_t) m * 4) || tmp.get(&len_sorted, (size_t) m * 4) || tmp.get(&ids, (size_t) m * 4) ||
+	int * len, * len_sorted, * ids, * win_off;
+	if (tmp.get(&len, (size_t) m * 4) || tmp.get(&len_sorted, (size_t) m * 4) || tmp.get(&ids, (size_t) m * 4) ||
 	    tmp.get(&win_off, (size_t) (num_windows + 1) * 4))
 		return 1;
-	if (rp_host[0] != 0)
-	{
-		set_error("sell_delta_convert_device: row_ptr must start at 0");
-		return 1;
-	}
-	HIP_TRY(hipMemcpy(rp, rp_host, (size_t) (m + 1) * 4, hipMemcpyHostToDevice));
-	if (nnz)
-	{
-		HIP_TRY(hipMemcpy(ci, ci_host, (size_t) nnz * 4, hipMemcpyHostToDevice));
-		HIP_TRY(hipMemcpy(va, va_host, (size_t) nnz * 8, hipMemcpyHostToDevice));
-	}
 	int * row_of_sorted = nullptr;
 	HIP_TRY(hipMalloc(&row_of_sorted, (size_t) std::max<long>(m, 1) * 4 + STREAM_SLACK * 4));
 	Scratch out_guard;                                 // frees the outputs if anything below fails
@@ -350,6 +339,32 @@ sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, c
 	*nnz_ext_out = nnz_ext;
 	*idx_bytes_out = idx_bytes;
 	return 0;
+}
+
+// The same from HOST arrays: upload, convert, drop the uploaded copy.
+int
+sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
+		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
+		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out)
+{
+	Scratch up;
+	int * rp, * ci;
+	double * va;
+	if (up.get(&rp, (size_t) (m + 1) * 4) || up.get(&ci, (size_t) nnz * 4) || up.get(&va, (size_t) nnz * 8))
+		return 1;
+	if (rp_host[0] != 0)
+	{
+		set_error("sell_delta_convert_device: row_ptr must start at 0");
+		return 1;
+	}
+	HIP_TRY(hipMemcpy(rp, rp_host, (size_t) (m + 1) * 4, hipMemcpyHostToDevice));
+	if (nnz)
+	{
+		HIP_TRY(hipMemcpy(ci, ci_host, (size_t) nnz * 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(va, va_host, (size_t) nnz * 8, hipMemcpyHostToDevice));
+	}
+	return sell_delta_convert_resident(f32, m, n_cols, nnz, sigma, rp, ci, va, d_row_of_sorted_out, d_desc_out, d_idx_out, d_val_out, val_ptr_host,
+			mode_counts, nnz_ext_out, idx_bytes_out);
 }
 
 }  // namespace spmv

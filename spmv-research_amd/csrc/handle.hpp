@@ -93,6 +93,8 @@ namespace spmv {
 
 // ---- device memory helpers (handle.hip)
 int dev_alloc_bytes(void ** p, size_t bytes);
+int build_sell_delta_resident(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * d_rp, const int * d_ci, const double * d_va);   // build_sell.hip
+void init_handle(spmv_mi355x_matrix * A, int format, int precision, int device, const spmv_mi355x_opts & o, long m, long n, long nnz);   // spmv_mi355x.hip
 int ensure_x(spmv_mi355x_matrix * A);                                    // spmv_mi355x.hip: stream + the handle's own (zeroed) x
 int tune_placement(spmv_mi355x_matrix * A);                              // placement.hip: move y, x and the side arrays to better blocks of HBM
 int dev_alloc_output(spmv_mi355x_matrix * A, void ** p, size_t bytes);   // placement.hip: a vector A's SpMV writes (placed by timing, zero-filled)

@@ -87,6 +87,11 @@ int sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigm
 		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
 		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out);
 
+// the same on a CSR already resident in device memory (rp, ci, va are device pointers; va fp64)
+int sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp, const int * ci,
+		const double * va, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
+		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out);
+
 // ---- COO (kernels_coo.hip)
 int coo_wave_items(int items_per_lane);                                // entries per wavefront
 int launch_coo(bool f32, int items_per_lane, const int * rowind, const int * col, const void * val, const void * x, void * y,

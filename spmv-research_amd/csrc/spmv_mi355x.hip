@@ -17,6 +17,26 @@ set_error(const char * fmt, ...)
 	va_end(ap);
 }
 
+// what every constructor of a handle starts from: identity, sizes, launch policy
+void
+init_handle(spmv_mi355x_matrix * A, int format, int precision, int device, const spmv_mi355x_opts & o, long m, long n, long nnz)
+{
+	A->format = format;
+	A->precision = precision;
+	A->f32 = (precision == SPMV_MI355X_F32);
+	A->vbytes = A->f32 ? 4 : 8;
+	A->device = device;
+	A->placement_off = o.placement == 2;
+	A->n = n;
+	A->m = m;
+	A->nnz = nnz;
+	A->csr_mem_footprint = (double) nnz * (A->vbytes + 4) + (double) (m + 1) * 4;
+	A->remap = (o.xcd_remap == 2) ? 0 : (o.xcd_remap == 3) ? 2 : (o.xcd_remap == 1) ? 1 : -1;   // -1 = auto, resolved per kernel
+	const double stream_bytes = (double) nnz * (A->vbytes + 4);
+	A->cfg.nt = (o.nontemporal == 1) ? 1 : (o.nontemporal == 2) ? 0 : (stream_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
+	A->cfg.beta = 0;
+}
+
 // the handle's own (zeroed) input vector. No stream of its own here: callers of the device-pointer entry points bring theirs, and with
 // several processes on one GPU every extra hardware queue costs (4 gloo ranks on one MI355X: halo exchange 2.4 -> 40 ms per step)
 int
@@ -135,22 +155,7 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 		return 1;
 
 	spmv_mi355x_matrix * A = new spmv_mi355x_matrix();
-	A->format = format;
-	A->precision = precision;
-	A->f32 = (precision == SPMV_MI355X_F32);
-	A->vbytes = A->f32 ? 4 : 8;
-	A->device = device;
-	A->placement_off = o.placement == 2;
-	A->n = n;
-	A->m = in.m;
-	A->nnz = in.nnz;
-	A->csr_mem_footprint = (double) in.nnz * (A->vbytes + 4) + (double) (in.m + 1) * 4;
-
-	// ---- launch policy
-	A->remap = (o.xcd_remap == 2) ? 0 : (o.xcd_remap == 3) ? 2 : (o.xcd_remap == 1) ? 1 : -1;   // -1 = auto, resolved per kernel
-	const double stream_bytes = (double) in.nnz * (A->vbytes + 4);
-	A->cfg.nt = (o.nontemporal == 1) ? 1 : (o.nontemporal == 2) ? 0 : (stream_bytes > 192.0 * 1024 * 1024 ? 1 : 0);
-	A->cfg.beta = 0;
+	init_handle(A, format, precision, device, o, in.m, n, in.nnz);
 
 	// ---- the format's constructor (= csr_to_format of the reference's backends)
 	int rc;

@@ -142,6 +142,14 @@ def _chunks(lens, max_nnz):
     return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
+def _streamable(c, pieces):
+    """Several pieces become ONE handle through the engine's device-resident CSR stream when the format allows it (SELL-64 delta
+    layout, what sell_c_sigma picks for matrices of this size); otherwise every piece becomes its own handle."""
+    o = c.opts
+    return (pieces > 1 and c.fmt == "sell_c_sigma" and o.get("sell_c", 64) in (0, 64) and o.get("sell_delta", 0) != 2
+            and o.get("convert_on", 0) != 2 and o.get("sell_window", 0) != 1 and not c.args.piece_handles)
+
+
 def _merge_samples(sa, sb):
     """Samples of the same rows taken from the local-column and the remote-column half of a block: one sample per row."""
     assert len(sa) == len(sb)
@@ -214,23 +222,38 @@ class RowsVariant:
         self.t_gen = self.t_conv = 0.0
         lens = np.diff(np.asarray(c.src.row_ptr[self.r0:self.r1 + 1], np.int64))
         pieces = _chunks(lens, c.args.host_chunk_nnz)
-        for k, (i0, i1) in enumerate(pieces):
-            a0, a1 = self.r0 + i0, self.r0 + i1
-            halves = []
-            for keep in ((1, 0) if c.args.overlap else (None,)):
+        use_stream = _streamable(c, len(pieces))          # several pieces -> ONE handle converted from a device-resident CSR
+        built = []                                        # per half: [(handle, first row)], samples
+        for keep in ((1, 0) if c.args.overlap else (None,)):
+            mats, smp = [], []
+            st = E.CsrStream(lm, self.n_x, int(lens.sum())) if use_stream else None      # capacity: the unfiltered block bounds either half
+            for k, (i0, i1) in enumerate(pieces):
+                a0, a1 = self.r0 + i0, self.r0 + i1
                 t0 = time.time()
                 blk = c.src.block(a0, a1) if keep is None else c.src.block_filtered(a0, a1, self.r0, self.r1, keep)
                 D.to_padded_columns(blk["col_idx"], self.offsets, self.padded)   # x lives as `world` slices padded to a common length
                 if keep != 1:
                     touched[blk["col_idx"]] = True
                 self.t_gen += time.time() - t0
-                smp = _take_samples(blk, i0, self.col_map, max(2000 // len(pieces), 50), seed=1 + k)
+                smp += _take_samples(blk, i0, self.col_map, max(2000 // len(pieces), 50), seed=1 + k)
                 t0 = time.time()
-                halves.append((E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], i1 - i0, self.n_x, c.fmt, c.np_dtype, **c.opts), smp))
+                if st is not None:
+                    st.append(blk["row_ptr"], blk["col_idx"], blk["values"])
+                else:
+                    mats.append((E.Matrix(blk["row_ptr"], blk["col_idx"], blk["values"], i1 - i0, self.n_x, c.fmt, c.np_dtype, **c.opts), i0))
                 self.t_conv += time.time() - t0
                 del blk
-            self.samples += halves[0][1] if len(halves) == 1 else _merge_samples(halves[0][1], halves[1][1])
-            self.launches.append((halves[0][0], halves[1][0] if len(halves) > 1 else None, i0))
+            if st is not None:
+                t0 = time.time()
+                mats = [(st.finish(c.fmt, c.np_dtype, **c.opts), 0)]
+                self.t_conv += time.time() - t0
+            built.append((mats, smp))
+        if len(built) == 1:
+            self.samples = built[0][1]
+            self.launches = [(M, None, first) for M, first in built[0][0]]
+        else:
+            self.samples = _merge_samples(built[0][1], built[1][1])
+            self.launches = [(ml, mr, first) for (ml, first), (mr, _f) in zip(built[0][0], built[1][0])]
         self.mats = [M for l in self.launches for M in l[:2] if M is not None]
         _rss("rows: handles built")
         self.build_peak_rss_gib = peak.gib()
@@ -443,11 +466,17 @@ class GraphVariant:
                 continue
             lens = np.asarray(c.src.row_ptr, np.int64)[rws.astype(np.int64) + 1] - np.asarray(c.src.row_ptr, np.int64)[rws]
             pieces = _chunks(lens, c.args.host_chunk_nnz)
+            st = E.CsrStream(len(rws), n, int(lens.sum())) if _streamable(c, len(pieces)) else None
             for j, (i0, i1) in enumerate(pieces):                 # piece by piece: the host holds one piece of the block at a time
                 b = c.src.rows(rws[i0:i1])
                 self.samples += _take_samples(b, first + i0, None, max(1000 // len(pieces), 50), seed=1 + 16 * k + j)
-                self.launches.append((E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n, c.fmt, c.np_dtype, **c.opts), first + i0, phase))
+                if st is not None:
+                    st.append(b["row_ptr"], b["col_idx"], b["values"])
+                else:
+                    self.launches.append((E.Matrix(b["row_ptr"], b["col_idx"], b["values"], b["m"], n, c.fmt, c.np_dtype, **c.opts), first + i0, phase))
                 del b
+            if st is not None:                                    # ONE handle for the part, converted on the GPU from the resident CSR
+                self.launches.append((st.finish(c.fmt, c.np_dtype, **c.opts), first, phase))
         self.mats = [l[0] for l in self.launches]
         _rss("graph: handles built")
         self.build_peak_rss_gib = max(self.build_peak_rss_gib, peak.gib())

@@ -45,6 +45,7 @@ SYMBOLS = [
     "spmv_mi355x_partitioned_offsets", "spmv_mi355x_partitioned_format_name", "spmv_mi355x_partitioned_exchange",
     "spmv_mi355x_partitioned_mem_footprint",
     "spmv_mi355x_upload_y", "spmv_mi355x_output_alloc", "spmv_mi355x_output_free",
+    "spmv_mi355x_csr_stream_begin", "spmv_mi355x_csr_stream_append", "spmv_mi355x_create_from_stream", "spmv_mi355x_csr_stream_discard",
 ]
 
 _lib = None
@@ -137,6 +138,52 @@ class OutputVector:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+def _make_opts(opts):
+    o = Opts()
+    o.struct_size = C.sizeof(Opts)
+    o.device = -1
+    for k, v in opts.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown option {k}")
+        setattr(o, k, v)
+    return o
+
+
+class CsrStream:
+    """A CSR assembled in device memory from pieces of consecutive rows (include/spmv_mi355x.h "a handle from a CSR that arrives in
+    pieces"): append(row_ptr, col_idx, values) per piece, finish(fmt, dtype, **opts) -> Matrix. The host never holds more than a
+    piece. SELL-C-sigma (64-row slices, delta layout) only."""
+
+    def __init__(self, m, n, nnz_capacity, device=-1):
+        self.s = C.c_void_p()
+        _check(lib().spmv_mi355x_csr_stream_begin(C.byref(self.s), C.c_int(device), C.c_long(m), C.c_long(n), C.c_long(nnz_capacity)))
+
+    def append(self, row_ptr, col_idx, values):
+        row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+        col_idx = np.ascontiguousarray(col_idx, np.int32)
+        values = np.ascontiguousarray(values, np.float64)
+        _check(lib().spmv_mi355x_csr_stream_append(self.s, C.c_long(len(row_ptr) - 1), _p(row_ptr), _p(col_idx), _p(values)))
+
+    def finish(self, fmt="sell_c_sigma", dtype=np.float64, **opts):
+        o = _make_opts(opts)
+        h = C.c_void_p()
+        s, self.s = self.s, None                       # consumed, whatever happens
+        fmt_id = FORMATS[fmt] if isinstance(fmt, str) else fmt
+        _check(lib().spmv_mi355x_create_from_stream(C.byref(h), s, fmt_id, F64 if np.dtype(dtype) == np.float64 else F32, C.byref(o)))
+        return Matrix(None, None, None, 0, 0, fmt, dtype, _handle=h)
+
+    def discard(self):
+        if getattr(self, "s", None):
+            lib().spmv_mi355x_csr_stream_discard(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.discard()
         except Exception:
             pass
 
@@ -237,7 +284,12 @@ class PartitionedMatrix:
 class Matrix:
     """One converted matrix on one GPU = the reference's `struct Matrix_Format` instance."""
 
-    def __init__(self, row_ptr, col_idx, values, m, n, fmt="csr_vector", dtype=np.float64, **opts):
+    def __init__(self, row_ptr, col_idx, values, m, n, fmt="csr_vector", dtype=np.float64, _handle=None, **opts):
+        if _handle is not None:                        # CsrStream.finish(): the handle exists already
+            self.dtype = np.dtype(dtype)
+            self.h = _handle
+            self._describe()
+            return
         row_ptr = np.ascontiguousarray(row_ptr, np.int32)
         col_idx = np.ascontiguousarray(col_idx, np.int32)
         values = np.ascontiguousarray(values, np.float64)
@@ -254,6 +306,9 @@ class Matrix:
         _check(lib().spmv_mi355x_create(C.byref(self.h), fmt_id, F64 if self.dtype == np.float64 else F32,
                                         C.c_long(m), C.c_long(n), C.c_long(len(col_idx)),
                                         _p(row_ptr), _p(col_idx), _p(values), C.byref(o)))
+        self._describe()
+
+    def _describe(self):
         L = lib()
         self.m = L.spmv_mi355x_rows(self.h)
         self.n = L.spmv_mi355x_cols(self.h)

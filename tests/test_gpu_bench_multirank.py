@@ -40,6 +40,8 @@ CASES = [
     (3, ["--scale", "0.01", "--host-chunk-nnz", "400000"], None, ["rows+allgather", "graph+halo"]),
     (2, ["--scale", "0.01", "--host-chunk-nnz", "300000", "--overlap", "0"], None, ["rows+allgather", "graph+halo"]),
     (2, ["--workload", "cant", "--scale", "0.3", "--host-chunk-nnz", "200000"], "rows", None),
+    # ... and the same with one handle PER PIECE (what formats without a device-side conversion fall back to)
+    (2, ["--scale", "0.01", "--host-chunk-nnz", "300000", "--piece-handles"], None, ["rows+allgather", "graph+halo"]),
 ]
 
 

@@ -655,3 +655,42 @@ def test_placement_moves_index_arrays_safely(eng, oracle):
     den = np.array([np.dot(np.abs(a[i * k:(i + 1) * k]), np.abs(x[ci[i * k:(i + 1) * k]])) for i in sample])
     assert np.all(np.abs(y[sample] - ref) <= 1e-12 * den)
     A.close()
+
+
+def test_handle_from_a_csr_that_arrives_in_pieces(eng, oracle):
+    """spmv_mi355x_create_from_stream: rows appended piece by piece to a device-resident CSR give the SAME handle as create() on the
+    whole matrix (same format name, same footprint, bit-identical y), fp64 and fp32; the pieces are validated as they pass."""
+    import spmv_host as H
+    A = H.gen_kkt(22)                                    # 24 k rows: one lane per row, several sigma windows
+    rp, ci, a, m, n = A["row_ptr"], A["col_idx"], A["values"], A["m"], A["n"]
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    cuts = [0, 1, 700, 701, 9000, m - 5, m]               # ragged pieces, one of a single row
+    for dtype in (np.float64, np.float32):
+        whole = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_window=2)
+        st = eng.CsrStream(m, n, int(rp[m]) + 1000)       # capacity is an upper bound
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            s, e = int(rp[r0]), int(rp[r1])
+            st.append(rp[r0:r1 + 1] - s, ci[s:e], a[s:e])
+        pieces = st.finish("sell_c_sigma", dtype)
+        assert pieces.format_name == whole.format_name and pieces.mem_footprint == whole.mem_footprint
+        assert (pieces.m, pieces.n, pieces.nnz) == (m, n, int(rp[m]))
+        assert np.array_equal(pieces.spmv(x.astype(dtype)), whole.spmv(x.astype(dtype)))
+        pieces.close()
+        whole.close()
+    # validation: wrong order of things
+    st = eng.CsrStream(4, 4, 10)
+    with pytest.raises(eng.SpmvError, match="start at 0"):
+        st.append(np.array([1, 2], np.int32), np.array([0], np.int32), np.ones(1))
+    with pytest.raises(eng.SpmvError, match="out of range"):
+        st.append(np.array([0, 1], np.int32), np.array([9], np.int32), np.ones(1))
+    st.append(np.array([0, 1, 2], np.int32), np.array([0, 3], np.int32), np.ones(2))
+    with pytest.raises(eng.SpmvError, match="2 of 4 rows"):
+        st.finish("sell_c_sigma")
+    st = eng.CsrStream(2, 2, 4)
+    st.append(np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32), np.ones(2))
+    with pytest.raises(eng.SpmvError, match="SELL-C-sigma only"):
+        st.finish("csr_vector")
+    st = eng.CsrStream(2, 2, 1)
+    with pytest.raises(eng.SpmvError, match="capacity"):
+        st.append(np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32), np.ones(2))
+    st.discard()
