@@ -184,6 +184,8 @@ tune_placement(spmv_mi355x_matrix * A)
 		return 0;
 	const auto c0 = std::chrono::steady_clock::now();
 	struct Slot { void ** p; const char * name; size_t size, off; };
+	// every device array a kernel READS that can reach 16 MiB, plus the handle's own vectors (keep in step with handle.hpp; an array
+	// missing here simply stays where it is)
 	Slot all[] = {{&A->d_y, "y", 0, 0}, {&A->d_x, "x", 0, 0}, {&A->d_val, "val", 0, 0}, {(void **) &A->d_sell_idx, "sell_idx", 0, 0},
 	              {(void **) &A->d_col, "col", 0, 0}, {(void **) &A->d_row_of_sorted, "row_of_sorted", 0, 0}, {(void **) &A->d_coob_ent, "coob_ent", 0, 0},
 	              {(void **) &A->d_row_ptr, "row_ptr", 0, 0}, {(void **) &A->d_col16, "col16", 0, 0}, {(void **) &A->d_sell_desc, "sell_desc", 0, 0},
