@@ -64,7 +64,8 @@ SMALL_CONFIGS = ("cant", "scircuit", "pwtk", "soc-LiveJournal1")
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000,
+                    help="timed steps; the default covers ~1.3 s of the headline kernel, which alternates between two levels 5.5 %% apart in stretches of 0.1-0.4 s (profiles/r02_placement.md §6): a shorter window measures whichever level it lands in")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="nlpkkt240",
                     help="cant | scircuit | pwtk | soc-LiveJournal1 | nlpkkt240 (synthetic twins)")
