@@ -108,7 +108,7 @@ def parse(argv=None):
                          "host copy of the matrix never exceeds a piece; 0 = the whole block at once")
     ap.add_argument("--piece-handles", action="store_true",
                     help="N>1: one handle per piece instead of one handle converted from the pieces in device memory (tests)")
-    ap.add_argument("--idle-after-placement", type=float, default=3.0,
+    ap.add_argument("--idle-after-placement", type=float, default=6.0,
                     help="seconds without launches after the engine has placed the vectors: the driver clears the ~165 GiB the search "
                          "returned in the background, which slows launches by up to 5.5 %% until it is done (profiles/r02_placement.md §6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -261,7 +261,7 @@ def sampled_row_check(yh, rp, ci, va, x_host, np_dtype, col_map=None, count=2000
     return max_rel, samp
 
 
-def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_warm_seconds=0.0, idle_after_placement=3.0):
+def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_warm_seconds=0.0, idle_after_placement=6.0):
     """Build one handle, run warm-up + `steps` back-to-back launches timed by HIP events on the launch stream, check sampled
     rows. Returns a dict with the measured figures and leaves nothing on the device."""
     np_dtype = np.float64 if dts == "f64" else np.float32
@@ -280,8 +280,9 @@ def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_war
     t_place = time.time() - t0
     if t_place > 0.15 and idle_after_placement > 0:
         # the placement pass has just returned ~165 GiB of ballast and unused sites to the driver, which clears freed memory in the
-        # background: for the next 2-3 s launches alternate between the normal level and one 5.5 % slower (time series in
-        # profiles/r02_placement.md §6); after a couple of idle seconds they are stable. Not part of any timed region.
+        # background: launched into that, the kernel alternates between its normal level and one 5.5 % slower for 4-5 s; after
+        # 5.5 idle seconds it is stable from the first batch on (time series in profiles/r02_placement.md §6). Not part of any timed
+        # region; reported in setup_s.
         time.sleep(idle_after_placement)
         t_place += idle_after_placement
     xp, yp = M.x_device(), M.y_device()
