@@ -178,7 +178,8 @@ int  spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host);      /* 
  * points the same for their vectors (bytes >= (rows + 64) values; smaller or < 32 MiB: a plain allocation). Zero-filled.
  * The search holds up to ~165 GiB of the device's free memory for its duration (ballast between the candidate sites; it never
  * takes the last 8 GiB and stops early when less is free) and returns everything but the chosen sites; the driver clears returned
- * memory in the background, which slows the next ~3 s of launches by up to 5 % (bench.py idles through it).
+ * memory in the background: kernels launched into that alternate between their normal time and one 5.5 % longer for 4-5 s; after
+ * 5.5 s without launches the device is done (bench.py idles through it; profiles/r02_placement.md §6).
  * SPMV_MI355X_PLACEMENT=0 turns the search off, =2 reports it on stderr. No reference counterpart (the reference's GPU
  * backends hipMalloc their vectors in the constructor, GPU_clean/csr_rocm_vector.cpp:77-86). */
 int  spmv_mi355x_output_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out);
