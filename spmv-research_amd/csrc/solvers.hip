@@ -493,20 +493,6 @@ struct DeviceBuffers {
 		*out = (P *) p;
 		return 0;
 	}
-	template <typename P>
-	int alloc_output(spmv_mi355x_matrix * A, P ** out, size_t bytes)         // a vector A's SpMV writes: placed by the engine
-	{
-		void * p = nullptr;
-		if (A ? spmv_mi355x_output_alloc(A, bytes, &p) : (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess))
-		{
-			if (!A)
-				set_error("hipMalloc of %zu bytes failed", bytes);
-			return 1;
-		}
-		ptrs.push_back(p);
-		*out = (P *) p;
-		return 0;
-	}
 };
 
 // Jacobi preconditioner: the first stored entry of row i whose column is i (bench_cg.cpp:114-134).
@@ -564,15 +550,15 @@ solve(int method, spmv_mi355x_matrix * A, const spmv_mi355x_dist_ops * dist, lon
 
 	T * b, * K, * x, * x_best, * r, * r_explicit, * p, * Ap;
 	T * r0 = nullptr, * y = nullptr, * z = nullptr, * s = nullptr, * v = nullptr;
-	for (T ** q : {&b, &K, &x, &x_best, &r, &r_explicit, &p})
+	// Plain allocations, the SpMV outputs (Ap, v) included: the engine's placement search (placement.hip) costs ~1 s and leaves the
+	// driver clearing 160 GiB for seconds afterwards — more than a solve of a few hundred iterations takes (measured: 0.27 instead of
+	// 0.24 ms per CG iteration on the 160^3 stencil right after it). A caller who solves many systems with one handle can hand in
+	// vectors from spmv_mi355x_output_alloc through the device-pointer entry points instead.
+	for (T ** q : {&b, &K, &x, &x_best, &r, &r_explicit, &p, &Ap})
 		ABI_TRY(buf.alloc(q, vb));
-	ABI_TRY(buf.alloc_output(dist ? nullptr : A, &Ap, vb + 64 * sizeof(T)));                          // the SpMV outputs
 	if (method == 1)
-	{
-		for (T ** q : {&r0, &y, &z, &s})
+		for (T ** q : {&r0, &y, &z, &s, &v})
 			ABI_TRY(buf.alloc(q, vb));
-		ABI_TRY(buf.alloc_output(dist ? nullptr : A, &v, vb + 64 * sizeof(T)));
-	}
 	double * part, * history = nullptr;
 	SolverState * st;
 	ABI_TRY(buf.alloc(&part, sizeof(double) * NUM_SLOTS * MAX_PART));
