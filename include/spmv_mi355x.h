@@ -173,7 +173,8 @@ int  spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host);      /* 
 /* The 288 GiB of an MI355X behave as 32 GiB regions, and the same kernel on the same matrix and x takes 1.28, 1.30 or 1.42 ms
  * (nlpkkt240 twin) depending only on which region y lives in; which memory an allocation gets is the driver's choice
  * (profiles/r02_placement.md). A vector the handle's SpMV writes is therefore placed by timing the handle's own
- * kernel on it: when a candidate from deeper in the pool is clearly faster, it replaces the first one. The handle's own y
+ * kernel on it: when a candidate from deeper in the pool is clearly faster, it replaces the first one. (The handle's own pass also
+ * moves its arrays of up to 8 GiB — value array, index arrays, x — the same way.) The handle's own y
  * (spmv_mi355x_y_device, used by spmv_mi355x_spmv) is placed this way; output_alloc gives callers of the device-pointer entry
  * points the same for their vectors (bytes >= (rows + 64) values; smaller or < 32 MiB: a plain allocation). Zero-filled.
  * The search holds up to ~165 GiB of the device's free memory for its duration (ballast between the candidate sites; it never

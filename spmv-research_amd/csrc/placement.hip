@@ -173,8 +173,8 @@ placement_map(spmv_mi355x_matrix * A)
 
 }   // namespace
 
-// One pass of coordinate descent over WHERE the handle's arrays live. The largest array (the value stream) stays; every other
-// array of 16 MiB .. 1 GiB (y, x, index bytes, row permutation, ...) is tried at up to ten sites taken 16 GiB apart from the pool
+// Coordinate descent over WHERE the handle's arrays live: every array of 16 MiB .. 8 GiB (the value stream first, then y, x, index
+// bytes, row permutation, ...; larger arrays stay and the others are placed against them) is tried at up to ten sites taken 16 GiB apart
 // (a D2D copy and six launches per trial) and stays at the site where the handle's kernel ran fastest, if that beats where it
 // was by 2 %. Sites that end up unused, the ballast between them and the originals of moved arrays are returned.
 int
@@ -204,7 +204,9 @@ tune_placement(spmv_mi355x_matrix * A)
 	std::vector<Slot *> movable;
 	size_t site_bytes = 0;
 	bool anchored = false;
-	static const size_t cap = getenv("SPMV_MI355X_PLACEMENT_CAP_GIB") ? (size_t) atol(getenv("SPMV_MI355X_PLACEMENT_CAP_GIB")) << 30 : (size_t) 1 << 30;
+	// arrays above the cap stay where they are (the others are placed against them). 8 GiB: the headline's 5.7 GiB value array takes part
+	// (worth 1-2 %: 1.264-1.270 against 1.280-1.294 ms); the sites and the ballast between them still add up to ~160 GiB
+	static const size_t cap = getenv("SPMV_MI355X_PLACEMENT_CAP_GIB") ? (size_t) atol(getenv("SPMV_MI355X_PLACEMENT_CAP_GIB")) << 30 : (size_t) 8 << 30;
 	for (Slot & sl : all)
 	{
 		if (sl.size == largest && !anchored && sl.p != &A->d_y && sl.p != &A->d_x && sl.size > cap)
