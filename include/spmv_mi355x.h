@@ -98,7 +98,7 @@ typedef struct {
 	int  sell_group;        /* sell_window: slices per workgroup (1, 2, 4, 8 or 16; times sell_split at most 16 wavefronts); 0 = auto */
 	int  placement;         /* where y, x and the index arrays live relative to the value array ("output vectors placed by the
 	                           engine" below): 0 = auto (a tuning pass of ~250 launches at the first use of the handle's own
-	                           vectors when y is 32 MiB or more), 2 = off                                                        */
+	                           vectors when y is 8 MiB or more), 2 = off                                                         */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */
@@ -176,7 +176,7 @@ int  spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host);      /* 
  * kernel on it: when a candidate from deeper in the pool is clearly faster, it replaces the first one. (The handle's own pass also
  * moves its arrays of up to 8 GiB — value array, index arrays, x — the same way.) The handle's own y
  * (spmv_mi355x_y_device, used by spmv_mi355x_spmv) is placed this way; output_alloc gives callers of the device-pointer entry
- * points the same for their vectors (bytes >= (rows + 64) values; smaller or < 32 MiB: a plain allocation). Zero-filled.
+ * points the same for their vectors (bytes >= (rows + 64) values; smaller or < 8 MiB: a plain allocation). Zero-filled.
  * The search holds up to ~165 GiB of the device's free memory for its duration (ballast between the candidate sites; it never
  * takes the last 8 GiB and stops early when less is free) and returns everything but the chosen sites; the driver clears returned
  * memory in the background: kernels launched into that alternate between their normal time and one 5.5 % longer for 4-5 s; after
