@@ -56,7 +56,8 @@ NAMED_KERNEL = {
 }
 # further kernels reported beside the named and the best one ("also"): the CSR-order merge path on the graph matrix, so that the
 # record shows what the column-blocked layout buys over the literal kernel
-ALSO_KERNELS = {"soc-LiveJournal1": [("csr_merge", {"col_blocks": -2})], "scircuit": [("csr_vector", {"lanes_per_row": 64})]}
+ALSO_KERNELS = {"soc-LiveJournal1": [("csr_merge", {"col_blocks": -2})], "scircuit": [("csr_vector", {"lanes_per_row": 64})],
+                "cant": [("csr_stream", {})]}            # cant: the CSR-storage kernel with the x window in LDS (16-bit columns), beside the named csr_vector
 # configs 1-4: timed after the headline at N = 1
 SMALL_CONFIGS = ("cant", "scircuit", "pwtk", "soc-LiveJournal1")
 
