@@ -20,16 +20,8 @@ free_all(spmv_mi355x_matrix * A)
 	                 A->d_row_of_sorted, A->d_rowind, A->d_x, A->d_y, A->d_sell_desc, A->d_sell_idx, A->d_win_row, A->d_win_lo,
 	                 A->d_win_w, A->d_col16, A->d_coob_wg_rows, A->d_coob_range_row, A->d_coob_seg_blk, A->d_coob_range_blk, A->d_coob_ent, A->d_coob_range_long, A->d_coob_long_row, A->d_coob_carry, A->d_sellw_grp};
 	for (void * p : ptrs)
-	{
-		bool inside = false;                       // moved into a shared block by the placement pass: freed with the block
-		for (const auto & b : A->placed_blocks)
-			inside = inside || ((char *) p >= (char *) b.base && (char *) p < (char *) b.base + b.bytes);
-		if (p && !inside)
+		if (p)
 			(void) hipFree(p);
-	}
-	for (const auto & b : A->placed_blocks)
-		(void) hipFree(b.base);
-	A->placed_blocks.clear();
 	if (A->stream)
 		(void) hipStreamDestroy(A->stream);
 }

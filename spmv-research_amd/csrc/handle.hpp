@@ -73,8 +73,6 @@ struct spmv_mi355x_matrix {
 	void * d_x = nullptr;
 	void * d_y = nullptr;
 	bool placement_off = false;            // opts.placement == 2
-	struct PlacedBlock { void * base; size_t bytes; };
-	std::vector<PlacedBlock> placed_blocks;   // placement.hip: allocations that now hold several of the arrays above
 	const void * cached_x_host = nullptr;
 	bool y_downloaded = false;
 	double place_fast_us = 0;         // placement.hip: kernel time on an output vector known to sit in a fast region

@@ -225,113 +225,123 @@ tune_placement(spmv_mi355x_matrix * A)
 		return 0;
 	std::stable_sort(movable.begin(), movable.end(), [&](const Slot * a, const Slot * b) { return (a->size == largest) > (b->size == largest); });
 	const size_t ballast_bytes = site_bytes + ((size_t) 1 << 30) < BALLAST_STEP ? BALLAST_STEP - site_bytes : (size_t) 1 << 30;
-	std::vector<void *> ballast, sites;
+	// a site = one buffer per movable array, allocated back to back behind its ballast (so they share a block of HBM); every buffer
+	// is an allocation of its own: what an array does not move into is returned one by one at the end
+	std::vector<void *> ballast;
+	std::vector<std::vector<void *>> sites;
 	for (int s = 0; s < 10; s++)
 	{
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < ballast_bytes + site_bytes + KEEP_FREE)
 			break;
-		void * b = nullptr, * site = nullptr;
+		void * b = nullptr;
 		if (hipMalloc(&b, ballast_bytes) != hipSuccess)
 		{
 			(void) hipGetLastError();
 			break;
 		}
 		ballast.push_back(b);
-		if (hipMalloc(&site, site_bytes) != hipSuccess)
+		std::vector<void *> bufs(movable.size(), nullptr);
+		bool ok = true;
+		for (size_t k = 0; k < movable.size() && ok; k++)
+			if (hipMalloc(&bufs[k], movable[k]->size) != hipSuccess)
+			{
+				(void) hipGetLastError();
+				ok = false;
+			}
+		if (!ok)
 		{
-			(void) hipGetLastError();
+			for (void * q : bufs)
+				if (q)
+					(void) hipFree(q);
 			break;
 		}
-		sites.push_back(site);
+		sites.push_back(bufs);
 	}
 	const double ms_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3;
-	std::vector<int> used(sites.size(), 0);
-	std::vector<void *> to_free;
+	std::vector<void *> original(movable.size());
+	for (size_t k = 0; k < movable.size(); k++)
+		original[k] = *movable[k]->p;
 	double t_cur = kernel_us(A, A->d_x, A->d_y);
 	const double t_start = t_cur;
 	int rc = t_cur < 0;
+	const std::vector<std::vector<void *>> all_sites = sites;          // for the clean-up at the end
 	if (t_cur >= 0 && t_cur < 20.0)
-		movable.clear();                   // launch-bound: differences between sites drown in the noise
+		sites.clear();                     // launch-bound: differences between sites drown in the noise
 	// Two sweeps: what is best for y depends on where x and the index arrays end up (and the other way round)
-	for (int sweep = 0, moved_any = 1; sweep < 2 && moved_any && !rc; sweep++)
+	for (int sweep = 0, moved_any = 1; sweep < 2 && moved_any && !rc && !sites.empty(); sweep++)
 	{
-	moved_any = 0;
-	for (Slot * sl : movable)
-	{
-		if (rc)
-			break;
-		void * const orig = *sl->p;
-		int best = -1;
-		double t_best = t_cur;
-		if (setting() >= 2)
-			fprintf(stderr, "[spmv_mi355x] %-14s %5.0f MiB: %7.1f us where it is; at the sites:", sl->name, (double) sl->size / (1 << 20), t_cur);
-		for (size_t s = 0; s < sites.size() && !rc; s++)
+		moved_any = 0;
+		for (size_t k = 0; k < movable.size() && !rc; k++)
 		{
-			void * dst = (char *) sites[s] + sl->off;
-			if (dst == orig)                          // second sweep: the site it already lives at
-			{
-				if (setting() >= 2)
-					fprintf(stderr, " =");
-				continue;
-			}
-			// on the stream the trial launches use, and finished before they start: a kernel that read a half-copied index
-			// array would gather x out of bounds
-			if (hipMemcpyAsync(dst, orig, sl->size, hipMemcpyDeviceToDevice, A->stream) != hipSuccess || hipStreamSynchronize(A->stream) != hipSuccess)
-			{
-				set_error("placement: device copy failed: %s", hipGetErrorString(hipGetLastError()));
-				rc = 1;
-				break;
-			}
-			*sl->p = dst;
-			const double t = kernel_us(A, A->d_x, A->d_y);
-			if (t < 0)
-				rc = 1;
+			Slot * sl = movable[k];
+			void * const orig = *sl->p;
+			int best = -1;
+			double t_best = t_cur;
 			if (setting() >= 2)
-				fprintf(stderr, " %.0f", t);
-			if (t > 0 && t < t_best * 0.98)
+				fprintf(stderr, "[spmv_mi355x] %-14s %5.0f MiB: %7.1f us where it is; at the sites:", sl->name, (double) sl->size / (1 << 20), t_cur);
+			for (size_t s = 0; s < sites.size() && !rc; s++)
 			{
-				best = (int) s;
-				t_best = t;
+				void * dst = sites[s][k];
+				if (dst == orig)                          // second sweep: the site it already lives at
+				{
+					if (setting() >= 2)
+						fprintf(stderr, " =");
+					continue;
+				}
+				// on the stream the trial launches use, and finished before they start: a kernel that read a half-copied index
+				// array would gather x out of bounds
+				if (hipMemcpyAsync(dst, orig, sl->size, hipMemcpyDeviceToDevice, A->stream) != hipSuccess || hipStreamSynchronize(A->stream) != hipSuccess)
+				{
+					set_error("placement: device copy failed: %s", hipGetErrorString(hipGetLastError()));
+					rc = 1;
+					break;
+				}
+				*sl->p = dst;
+				const double t = kernel_us(A, A->d_x, A->d_y);
+				if (t < 0)
+					rc = 1;
+				if (setting() >= 2)
+					fprintf(stderr, " %.0f", t);
+				if (t > 0 && t < t_best * 0.98)
+				{
+					best = (int) s;
+					t_best = t;
+				}
 			}
+			if (best >= 0 && !rc)
+			{
+				// every site holds a faithful copy: the arrays the kernel reads never change, y is zeroed below
+				*sl->p = sites[(size_t) best][k];
+				t_cur = t_best;
+				moved_any = 1;
+			}
+			else
+				*sl->p = orig;
+			if (setting() >= 2)
+				fprintf(stderr, " -> %s, %.1f us\n", best >= 0 ? "moved" : "stays", t_cur);
 		}
-		if (best >= 0 && !rc)
-		{
-			*sl->p = (char *) sites[(size_t) best] + sl->off;
-			bool in_site = false;                  // an array that already lives in a site (second sweep) has no allocation of its own to return
-			for (void * st : sites)
-				in_site = in_site || ((char *) orig >= (char *) st && (char *) orig < (char *) st + site_bytes);
-			if (!in_site)
-				to_free.push_back(orig);
-			t_cur = t_best;
-			moved_any = 1;
-		}
-		else
-			*sl->p = orig;
-		if (setting() >= 2)
-			fprintf(stderr, " -> %s, %.1f us\n", best >= 0 ? "moved" : "stays", t_cur);
 	}
-	}
-	for (size_t s2 = 0; s2 < sites.size(); s2++)       // sites in use at the end
-		for (Slot * sl : movable)
-			if ((char *) *sl->p >= (char *) sites[s2] && (char *) *sl->p < (char *) sites[s2] + site_bytes)
-				used[s2] = 1;
 	if (!rc)
 		HIP_TRY(hipMemset(A->d_y, 0, (size_t) (A->m + 64) * A->vbytes));
 	HIP_TRY(hipDeviceSynchronize());
 	for (void * p : ballast)
 		(void) hipFree(p);
-	for (void * p : to_free)
-		(void) hipFree(p);
-	for (size_t s = 0; s < sites.size(); s++)
-		if (used[s])
-			A->placed_blocks.push_back({sites[s], site_bytes});
-		else
-			(void) hipFree(sites[s]);
+	// every site buffer an array did not end up in goes back, and so does the original of an array that moved: each array is again
+	// an allocation of its own, owned through the handle's pointer as before
+	for (size_t k = 0; k < movable.size(); k++)
+	{
+		void * const now = *movable[k]->p;
+		for (const auto & bufs : all_sites)
+			if (bufs[k] != now)
+				(void) hipFree(bufs[k]);
+		if (original[k] != now)
+			(void) hipFree(original[k]);
+	}
 	A->place_fast_us = t_cur;                      // later output vectors are held against this
 	if (setting() >= 2)
 		fprintf(stderr, "[spmv_mi355x] placement: %.1f -> %.1f us per SpMV, %zu sites, %.0f ms (%.0f ms of it allocating the sites)\n", t_start, t_cur,
-				sites.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3, ms_alloc);
+				all_sites.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3, ms_alloc);
 	if (!rc && setting() == 4)
 		return placement_map(A);
 	return rc;
