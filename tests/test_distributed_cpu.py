@@ -221,3 +221,19 @@ def test_matrix_free_partition_and_halo_lists(world):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_subranges_from_marks_equal_subranges_from_columns():
+    """A rank that builds its block piece by piece accumulates the 'touched' marks per piece (bench_multi.RowsVariant): the ranges cut
+    from the marks must be the ranges cut from the whole column list."""
+    import spmv_dist as D
+    rng = np.random.default_rng(8)
+    world, padded = 4, 100_000
+    cols = np.concatenate([rng.integers(0, 3_000, 500), padded + rng.integers(40_000, 41_000, 300), padded + rng.integers(90_000, 99_000, 50),
+                           3 * padded + rng.integers(0, padded, 2_000)]).astype(np.int64)
+    whole = D.needed_subranges(cols, padded, world, min_gap=1 << 12)
+    touched = np.zeros(world * padded, bool)
+    for piece in np.array_split(cols, 7):
+        touched[piece] = True
+    np.testing.assert_array_equal(D.subranges_of_touched(touched, padded, world, min_gap=1 << 12), whole)
+    assert whole[2].sum() == 0 and whole[1, :, 1].max() > 90_000        # peer 2 unused, peer 1 cut into its two regions
