@@ -23,6 +23,13 @@ per launch / mean kernel time from HIP events recorded on the launch stream over
 roofline.frac == roofline.frac_algorithmic is that CSR-normalised figure; roofline.frac_hbm_measured is the PMC
 traffic of the same kernel build / time / peak (only when profiles/traffic_*.json holds a record taken with these
 kernel sources and this format).
+
+Order of events at N = 1 (everything before the timed steps is reported under setup_s, none of it is timed): generate the twin ->
+convert (GPU) -> first use of the handle's own x / y: the engine places the vectors and its arrays in HBM by timing its own
+kernel at candidate sites (csrc/placement.hip; worth up to 13 % on this device, profiles/r02_placement.md) -> 6 s idle while the
+driver clears the memory that search returned -> W warm-up launches -> settle (batches until two agree within 0.5 %, >= 500
+launches; the reference driver warms GPU kernels with 1000 calls) -> EXACTLY K timed launches between HIP events, inside a
+synchronize bracket (K = 1000 by default: 1.3 s of the headline kernel).
 """
 import argparse
 import hashlib
