@@ -58,12 +58,12 @@ NAMED_KERNEL = {
     "scircuit": ("csr_vector", {"lanes_per_row": 64, "rows_per_group": 2}),   # config 2: CSR-Vector, one wavefront per row (two rows
                                                                              # of a wavefront in flight: 27.9 vs 40.5 us)
     "pwtk": ("sell_c_sigma", {}),                         # config 3: SELL-C-sigma fp32
-    "soc-LiveJournal1": ("csr_merge", {}),                # config 4: merge-based CSR (auto: merge-balanced column-blocked layout)
+    "soc-LiveJournal1": ("csr_merge", {}),                # config 4: merge-based CSR = the literal CSR-order merge path (merge.cpp:256-319)
     "nlpkkt240": ("csr_stream", {}),                      # config 5: row-partitioned CSR (plain CSR storage)
 }
-# further kernels reported beside the named and the best one ("also"): the CSR-order merge path on the graph matrix, so that the
-# record shows what the column-blocked layout buys over the literal kernel
-ALSO_KERNELS = {"soc-LiveJournal1": [("csr_merge", {"col_blocks": -2})], "scircuit": [("csr_vector", {"lanes_per_row": 64})],
+# further kernels reported beside the named and the best one ("also"): on the graph matrix the column-blocked layout with merge-path
+# balanced row ranges (what `csr_merge` runs when asked for it: col_blocks = -1) beside the best one (the same layout under `coo`)
+ALSO_KERNELS = {"soc-LiveJournal1": [("csr_merge", {"col_blocks": -1})], "scircuit": [("csr_vector", {"lanes_per_row": 64})],
                 "cant": [("csr_stream", {})]}            # cant: the CSR-storage kernel with the x window in LDS (16-bit columns), beside the named csr_vector
 # configs 1-4: timed after the headline at N = 1
 SMALL_CONFIGS = ("cant", "scircuit", "pwtk", "soc-LiveJournal1")
@@ -269,9 +269,24 @@ def sampled_row_check(yh, rp, ci, va, x_host, np_dtype, col_map=None, count=2000
     return max_rel, samp
 
 
-def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_warm_seconds=0.0, idle_after_placement=6.0):
-    """Build one handle, run warm-up + `steps` back-to-back launches timed by HIP events on the launch stream, check sampled
-    rows. Returns a dict with the measured figures and leaves nothing on the device."""
+def cold_launches(torch, M, xp, yp, sp, count=15, flush_bytes=1 << 30):
+    """Isolated launches with the caches flushed in between: a 1 GiB buffer (4x the 256 MiB Infinity Cache) is overwritten on the
+    launch stream before every single event-timed launch — the GPU analogue of the reference driver's CLEAR_CACHES
+    (bench_spmv.cpp:331-348). These times include the ramp-up and drain of one kernel on an idle chip. Median ms."""
+    flush = torch.empty(flush_bytes, dtype=torch.uint8, device="cuda")
+    ts = []
+    for i in range(count):
+        flush.fill_(i & 0xff)
+        ts.append(M.time_device(xp, yp, 1, sp))
+    del flush
+    return float(np.median(ts))
+
+
+def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_warm_seconds=0.0, idle_after_placement=6.0, windows=1,
+                cold=False):
+    """Build one handle, run warm-up + `windows` x `steps` back-to-back launches, each window timed by HIP events on the launch
+    stream inside a synchronize bracket, check sampled rows. Returns a dict with the measured figures (the MEDIAN window's) and leaves
+    nothing on the device."""
     np_dtype = np.float64 if dts == "f64" else np.float32
     t_dtype = torch.float64 if dts == "f64" else torch.float32
     vbytes = 8 if dts == "f64" else 4
@@ -312,10 +327,16 @@ def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_war
             break
     if os.environ.get("SPMV_BENCH_VERBOSE"):
         print("[bench] settle batches (ms): " + " ".join(f"{v:.4f}" for v in settle), file=sys.stderr)
-    t0 = time.perf_counter()
-    kernel_ms = M.time_device(xp, yp, steps, sp)                  # HIP events on the launch stream
-    torch.cuda.synchronize()
-    wall_ms = (time.perf_counter() - t0) / steps * 1e3
+    wins = []
+    for _ in range(max(1, windows)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k_ms = M.time_device(xp, yp, steps, sp)                   # HIP events on the launch stream
+        torch.cuda.synchronize()
+        wins.append(((time.perf_counter() - t0) / steps * 1e3, k_ms))
+    wins.sort()
+    wall_ms, kernel_ms = wins[len(wins) // 2]
+    cold_ms = cold_launches(torch, M, xp, yp, sp) if cold else None
     yh = M.download_y().astype(np.float64)
     max_rel, samp = sampled_row_check(yh, A["row_ptr"], A["col_idx"], A["values"], x_host, np_dtype)
     tol = 1e-12 if dts == "f64" else 1e-5
@@ -325,20 +346,27 @@ def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_war
     B = algorithmic_bytes(m, n, nnz, vbytes)
     out = dict(format_name=M.format_name, kernel=ki["name"], kernel_ms=kernel_ms, wall_ms=wall_ms, convert_s=t_conv,
                algorithmic_bytes=B, gbps=B / (kernel_ms * 1e-3) / 1e9, gflops=2.0 * nnz / (kernel_ms * 1e-3) / 1e9,
-               mem_footprint=M.mem_footprint, check=max_rel, yh=yh, samp=samp, x_host=x_host, place_s=t_place)
+               mem_footprint=M.mem_footprint, check=max_rel, yh=yh, samp=samp, x_host=x_host, place_s=t_place,
+               wall_ms_windows=[round(w[0], 6) for w in wins], cold_ms=cold_ms)
     M.close()
     return out
 
 
 def roofline_record(workload, dts, t, with_traffic=True):
-    """The "roofline" object of one timed kernel."""
+    """The "roofline" object of one timed kernel. ONE clock for every fraction: the wall time per step of the synchronize bracket
+    (= ms_per_step of the line); the HIP-event time of the same launches is kept beside it as kernel_ms."""
     traffic = load_traffic(workload, t["format_name"], dts, t["kernel"]) if with_traffic else None
     resident = t["algorithmic_bytes"] < INFINITY_CACHE_BYTES
-    frac = t["gbps"] / HBM_PEAK_GBPS
-    return {"bound": "hbm", "achieved": round(t["gbps"], 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(frac, 4),
+    ms = t["wall_ms"]
+    gbps = t["algorithmic_bytes"] / (ms * 1e-3) / 1e9
+    frac = gbps / HBM_PEAK_GBPS
+    return {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(frac, 4),
+            # CSR-normalised ("algorithmic") bytes: a format that stores fewer bytes than CSR scores above what it moves
             "frac_algorithmic": round(frac, 4),
-            "frac_hbm_measured": None if traffic is None else round(traffic / (t["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "traffic": traffic, "kernel": t["kernel"], "kernel_ms": round(t["kernel_ms"], 6),
+            # bytes the PMC passes saw move (profiles/traffic_*.json, stored per kernel-source fingerprint, not re-counted in this run)
+            "frac_hbm_measured": None if traffic is None else round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "traffic": traffic, "traffic_source": None if traffic is None else "profiles/traffic_*.json (rocprofv3 PMC pass of the same kernel sources)",
+            "kernel": t["kernel"], "kernel_ms": round(t["kernel_ms"], 6), "ms": round(ms, 6),
             "algorithmic_bytes_per_launch": int(t["algorithmic_bytes"]),
             # a working set under the 256 MiB Infinity Cache is served on-die when launched back to back: its GB/s is a cache
             # rate, not an HBM rate (DESIGN §5)
@@ -357,24 +385,40 @@ def run_small_configs(E, torch, H, args):
         bf, bo = DEFAULT_FORMAT[w], DEFAULT_OPTS.get(w, {})
         steps = args.configs_steps if A["nnz"] < 20_000_000 else max(20, args.configs_steps // 6)
         warm = 0.1 if A["nnz"] < 20_000_000 else 0.0
-        named = time_handle(E, torch, A, nf, dts, dict(no), steps, 20, min_warm_seconds=warm)
-        best = time_handle(E, torch, A, bf, dts, dict(bo), steps, 20, x_host=named["x_host"], min_warm_seconds=warm)
+        resident = algorithmic_bytes(A["m"], A["n"], A["nnz"], 8 if dts == "f64" else 4) < INFINITY_CACHE_BYTES
+        # cache-resident matrices also get a COLD figure (caches flushed before every isolated launch): the warm one is a cache rate
+        named = time_handle(E, torch, A, nf, dts, dict(no), steps, 20, min_warm_seconds=warm, cold=resident)
+        best = time_handle(E, torch, A, bf, dts, dict(bo), steps, 20, x_host=named["x_host"], min_warm_seconds=warm, cold=resident)
         rn, rb = roofline_record(w, dts, named), roofline_record(w, dts, best)
         also = []
         for af, ao in ALSO_KERNELS.get(w, []):
             t = time_handle(E, torch, A, af, dts, dict(ao), steps, 20, x_host=named["x_host"], min_warm_seconds=warm)
-            also.append({"kernel": t["kernel"], "format": t["format_name"], "ms": round(t["kernel_ms"], 6),
-                         "frac": round(t["gbps"] / HBM_PEAK_GBPS, 4), "traffic": load_traffic(w, t["format_name"], dts, t["kernel"])})
-        out.append({"workload": f"{w} ({'synthetic twin' if data == 'synthetic' else data})", "dtype": dts,
-                    "rows": int(A["m"]), "nnz": int(A["nnz"]), "algorithmic_bytes": int(named["algorithmic_bytes"]),
-                    "cache_resident": rn["cache_resident"],
-                    "named_kernel": named["kernel"], "named_format": named["format_name"], "named_ms": round(named["kernel_ms"], 6),
-                    "named_gflops": round(named["gflops"], 2), "named_frac": rn["frac"], "named_traffic": rn["traffic"],
-                    "best_kernel": best["kernel"], "best_format": best["format_name"], "best_ms": round(best["kernel_ms"], 6),
-                    "best_gflops": round(best["gflops"], 2), "best_frac": rb["frac"], "traffic": rb["traffic"],
-                    "frac_hbm_measured": rb["frac_hbm_measured"], "also": also,
-                    "check_max_err_over_abs_row": max(named["check"], best["check"]),
-                    "setup_s": round(t_gen + named["convert_s"] + best["convert_s"], 2)})
+            also.append({"kernel": t["kernel"], "format": t["format_name"], "ms": round(t["wall_ms"], 6), "kernel_ms": round(t["kernel_ms"], 6),
+                         "frac": roofline_record(w, dts, t, with_traffic=False)["frac"], "traffic": load_traffic(w, t["format_name"], dts, t["kernel"])})
+        rec = {"workload": f"{w} ({'synthetic twin' if data == 'synthetic' else data})", "dtype": dts,
+               "rows": int(A["m"]), "nnz": int(A["nnz"]), "algorithmic_bytes": int(named["algorithmic_bytes"]),
+               "cache_resident": rn["cache_resident"],
+               "named_kernel": named["kernel"], "named_format": named["format_name"], "named_ms": round(named["wall_ms"], 6),
+               "named_kernel_ms": round(named["kernel_ms"], 6),
+               "named_gflops": round(2.0 * A["nnz"] / (named["wall_ms"] * 1e-3) / 1e9, 2), "named_frac": rn["frac"], "named_traffic": rn["traffic"],
+               "best_kernel": best["kernel"], "best_format": best["format_name"], "best_ms": round(best["wall_ms"], 6),
+               "best_kernel_ms": round(best["kernel_ms"], 6),
+               "best_gflops": round(2.0 * A["nnz"] / (best["wall_ms"] * 1e-3) / 1e9, 2), "best_frac": rb["frac"], "traffic": rb["traffic"],
+               "frac_hbm_measured": rb["frac_hbm_measured"], "also": also,
+               "check_max_err_over_abs_row": max(named["check"], best["check"]),
+               "setup_s": round(t_gen + named["convert_s"] + best["convert_s"], 2)}
+        if resident:
+            B = named["algorithmic_bytes"]
+            rec.update({"named_cold_ms": round(named["cold_ms"], 6), "named_cold_frac": round(B / (named["cold_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "best_cold_ms": round(best["cold_ms"], 6), "cold_frac": round(B / (best["cold_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "cold": "isolated launches, a 1 GiB buffer overwritten before each (bench_spmv.cpp:331-348 CLEAR_CACHES); median of 15"})
+        if not args.no_cpu_baseline:
+            # the reference's CPU CSR kernel on the same matrix (whole matrix where it has <= 64 M non-zeros: config 1 IS this on cant)
+            saved = args.cpu_baseline_seconds
+            args.cpu_baseline_seconds = min(saved, 2.0)
+            rec["cpu_baseline"] = cpu_baseline(args, w, dts, A, named["x_host"], best["yh"])
+            args.cpu_baseline_seconds = saved
+        out.append(rec)
         del A, named, best
     return out
 
@@ -500,9 +544,12 @@ def main():
     t_gen = time.time() - t0
     m, n, nnz = A["m"], A["n"], A["nnz"]
     small = nnz < 20_000_000
+    # a short sample (the driver's --steps 20 is 25 ms of a kernel whose level moves by a few % over tenths of a second) is timed as
+    # 5 windows of K steps, each in its own synchronize bracket; the line carries the MEDIAN window and the spread
+    windows = 5 if args.steps < 200 else 1
     t = time_handle(E, torch, A, fmt, dts, opts, args.steps, args.warmup, min_warm_seconds=0.25 if small else 0.0,
-                    idle_after_placement=args.idle_after_placement)
-    ms_per_step = t["wall_ms"]                    # barrier + synchronize bracket around exactly K launches
+                    idle_after_placement=args.idle_after_placement, windows=windows)
+    ms_per_step = t["wall_ms"]                    # synchronize bracket around exactly K launches (the median window of `windows`)
     gflops = 2.0 * nnz / (ms_per_step * 1e-3) / 1e9
     B_alg = t["algorithmic_bytes"]
     wl = f"{workload} ({'synthetic twin' if data == 'synthetic' else data})" + ("" if args.scale == 1.0 else f" scale={args.scale}")
@@ -513,7 +560,8 @@ def main():
     result = {
         "metric": f"GFLOP/s (2*nnz/t, {'fp64' if dts == 'f64' else 'fp32'} SpMV y=A*x); achieved HBM GB/s and % of peak in 'roofline'",
         "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
+        "ms_per_step": round(ms_per_step, 6), "windows": windows, "ms_per_step_min": min(t["wall_ms_windows"]), "ms_per_step_max": max(t["wall_ms_windows"]),
+        "higher_is_better": True,
         "scaling": "strong",            # total work (one SpMV of the whole matrix) is fixed as N grows
         "vs_baseline": None, "dtype": dts, "data": "synthetic" if data == "synthetic" else data,
         "config": {"workload": wl, "format": t["format_name"], "rows": int(m), "cols": int(n), "nnz": int(nnz),

@@ -85,11 +85,12 @@ typedef struct {
 	                           y = (T + T^t - diag T) x. Expanded at create(); rows()/nnz() then report the expanded matrix */
 	int  rows_per_group;    /* CSR_VECTOR: consecutive rows a lane group keeps in flight together (1, 2 or 4; 2 and 4 need
 	                           lanes_per_row >= 8); 0 = auto                                                        */
-	int  col_blocks;        /* COO: 0 = row-sorted COO (the reference's layout); -1 = column-blocked layout for graph matrices with
-	                           blocks of ~384 KiB of x; > 0 = that many column blocks (at most 65 536 columns each). The rows are
-	                           dealt to workgroups that keep their y in LDS, the entries are ordered by column block (csrc/kernels_coo.hip).
-	                           CSR_MERGE: the same layout with merge-path-balanced row ranges: 0 = auto (taken when the x gathers
-	                           are scattered over a vector no L2 holds), -1 / > 0 = on, -2 = plain CSR-order merge path            */
+	int  col_blocks;        /* COO: 0 = row-sorted COO (the reference's layout); -1 = column-blocked layout for graph matrices: the rows are
+	                           dealt to workgroups that keep their y in LDS, a workgroup's entries are sorted by column and stored as one
+	                           dword each in full batches (csrc/kernels_coo.hip); > 0 = the same with a wave instruction's 64 entries kept
+	                           inside ceil(n / col_blocks) columns (tests). LDS atomics: sums to the tolerance, not bit-reproducible.
+	                           CSR_MERGE: 0 / -2 = the CSR-order merge path (deterministic); -1 / > 0 = the same column-blocked layout
+	                           with merge-path-balanced row ranges — never chosen unless asked for                                  */
 	int  sell_window;       /* SELL, 64-row slices: a workgroup owns a group of consecutive slices, copies the group's column window of
 	                           x into LDS and gathers from there; column indices are 16-bit offsets into the window (for banded /
 	                           FEM matrices; csrc/kernels_sell_window.hip). 0 = auto (when every group's window fits), 1 = on, 2 = off */

@@ -7,8 +7,9 @@ namespace spmv {
 // Column-blocked layout (opts.col_blocks; described in kernels_coo.hip). Built on the host: row ranges balanced by non-zeros
 // (COO: equal shares of the entries, as coo_kernel's waves) or by rows + non-zeros (merge path: equal shares of the merge
 // diagonal, merge.cpp:277-287), cut at chunk boundaries — by rows alone when a share would overflow a workgroup's LDS;
-// chunks of 16 rows dealt round-robin to the 32 workgroups of a range; rows longer than a workgroup's fair share / 8 are
-// split over the 32 workgroups; per workgroup a counting sort by column block and inside a block a sort by (column, row).
+// chunks of 16 rows dealt to the 32 workgroups of a range so that all get the same number of entries; rows longer than a
+// workgroup's fair share / 8 are split over the 32 workgroups; per workgroup a sort by (column, LDS slot) and a cut into full
+// batches whose wave instructions have a base column each.
 int
 build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va, int col_blocks, bool merge_balance)
 {
@@ -59,7 +60,17 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 	}
 	double v0 = 0;
 	const bool uniform = values_uniform(A, va, lnnz, &v0);
-	// ---- rows to split: longer than 1/8 of a workgroup's fair share of the entries (at most KMAX per range, in row order)
+	// ---- rows are dealt to the 32 workgroups of their range in chunks of CH consecutive rows (16: a chunk's y is one 128-byte line)
+	long CH = RND;
+	if (const char * e = getenv("SPMV_MI355X_COOB_CHUNK"))
+		if (atol(e) >= RND && atol(e) % RND == 0 && atol(e) <= cap)
+			CH = atol(e);
+	// ---- rows to split over the 32 workgroups of their range (each takes a contiguous piece of the row's entries): a row longer than
+	// 1/8 of a workgroup's fair share of the entries would unbalance the workgroup that owns it (the merge-path remedy, merge.cpp:302-318).
+	// A split row needs one LDS slot in EVERY workgroup of the range; KMAX slots are set aside for them, the longest rows go first.
+	// (Splitting more rows — every hub of a power-law graph — was tried and LOSES: 197 -> 250 us on the soc-LiveJournal1 twin with 1 400
+	// split rows per range although the workgroups' shares get more even; a workgroup then has a dense stretch of columns of its own,
+	// the 32 workgroups of an XCD drift apart in their sweep over x and their common window no longer fits the L2.)
 	long long_min = std::max<long>(256, lnnz / NT / 8);
 	if (const char * e = getenv("SPMV_MI355X_COOB_LONG_MIN"))      // tests: split ordinary rows of small matrices too
 		if (atol(e) >= 1)
@@ -67,13 +78,20 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 	std::vector<int> range_long((size_t) NR + 1, 0), long_row;
 	for (long r = 0; r < NR; r++)
 	{
-		int k = 0;
-		for (long row = range_row[r]; row < range_row[r + 1] && k < KMAX; row++)
+		const long r0 = range_row[r], r1 = range_row[r + 1];
+		std::vector<std::pair<int, int>> cand;                    // (-length, row): longest first, ties in row order
+		for (long row = r0; row < r1; row++)
 			if (rp[row + 1] - rp[row] >= long_min)
-			{
-				long_row.push_back((int) row);
-				k++;
-			}
+				cand.emplace_back(-(rp[row + 1] - rp[row]), (int) row);
+		if ((long) cand.size() > KMAX)
+		{
+			std::partial_sort(cand.begin(), cand.begin() + KMAX, cand.end());
+			cand.resize((size_t) KMAX);
+		}
+		const size_t at = long_row.size();
+		for (const auto & c : cand)
+			long_row.push_back(c.second);
+		std::sort(long_row.begin() + at, long_row.end());
 		range_long[r + 1] = (int) long_row.size();
 	}
 	const long NL = (long) long_row.size();
@@ -86,229 +104,219 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 		a = rp[row] + len * j / WGS;
 		b = rp[row] + len * (j + 1) / WGS;
 	};
-	// ---- how a range's rows are dealt to its 32 workgroups: chunks of CH rows, round-robin. CH = 16 (default): every workgroup sees
-	// the whole range's column structure, entries per block are even. SPMV_MI355X_COOB_CHUNK=0: ONE contiguous chunk per workgroup
-	// (fewer distinct x lines per workgroup on banded graphs, uneven block fill at the range's ends).
-	long CH = RND;
-	if (const char * e = getenv("SPMV_MI355X_COOB_CHUNK"))
+	// ---- the deal: longest-processing-time-first over a range's chunks, weighted by their entries (split rows excluded: every workgroup
+	// gets a 32nd of those anyway), at most `cap / CH` chunks per workgroup. Every workgroup of the launch then has the same number of
+	// entries to within a chunk's weight — a round-robin deal left the fullest workgroup of the soc-LiveJournal1 twin 7.7 % above the
+	// mean, and the launch takes as long as its fullest workgroup. A workgroup's chunks stay in row order (LDS slot = position).
+	std::vector<int> chunk_ptr((size_t) NT + 1, 0);
+	std::vector<int> chunk_row;                                   // first row of every chunk, workgroup after workgroup
 	{
-		if (atol(e) == 0)
+		std::vector<std::vector<int>> mine((size_t) NT);
+		#pragma omp parallel for num_threads(std::min<int>(spmv::host_threads(), (int) NR)) schedule(dynamic, 1)
+		for (long r = 0; r < NR; r++)
 		{
-			long widest = 0;
-			for (long r = 0; r < NR; r++)
-				widest = std::max<long>(widest, range_row[r + 1] - range_row[r]);
-			CH = std::max<long>(RND, ((widest + WGS - 1) / WGS + RND - 1) / RND * RND);
-		}
-		else if (atol(e) >= RND && atol(e) % RND == 0 && atol(e) <= cap)
-			CH = atol(e);
-	}
-	// ---- column blocks, per range (the 32 workgroups of a range walk the same blocks in step): every block spans at most 65 536
-	// columns (16-bit offsets). col_blocks > 0: uniform blocks of ceil(n / col_blocks) columns. col_blocks = -1: EQUI-DEPTH blocks —
-	// as many columns as hold one full batch of entries per workgroup (85 % of it on average: the deal is statistical), so that
-	// every step of the kernel is a full batch wherever the matrix is dense enough, and empty stretches of columns cost nothing.
-	std::vector<std::vector<int>> bstart((size_t) NR);
-	{
-		const long W = col_blocks > 0 ? std::max<long>(1, std::min<long>((n + col_blocks - 1) / col_blocks, 65536)) : 0;
-		const long target = (long) (0.85 * WGS * coo_blocked_batch_entries());
-		#pragma omp parallel num_threads(std::min<int>(spmv::host_threads(), (int) NR))
-		{
-			std::vector<int> hist;
-			#pragma omp for schedule(dynamic, 1)
-			for (long r = 0; r < NR; r++)
+			const long r0 = range_row[r], r1 = range_row[r + 1];
+			const long chunks = (r1 - r0 + CH - 1) / CH;
+			const long nlong = range_long[r + 1] - range_long[r];
+			const long cap_chunks = std::max<long>((chunks + WGS - 1) / WGS, cap / CH);
+			std::vector<std::pair<long, int>> w((size_t) chunks);     // (-entries, chunk)
+			for (long c = 0; c < chunks; c++)
 			{
-				const long e0 = rp[range_row[r]], e1 = rp[range_row[r + 1]];
-				std::vector<int> & bs = bstart[(size_t) r];
-				if (e1 == e0)
-					continue;
-				if (W > 0)
+				const long a = r0 + c * CH, bnd = std::min(r1, a + CH);
+				long cnt = rp[bnd] - rp[a];
+				if (nlong)
+					for (long row = a; row < bnd; row++)
+						if (is_long(r, row))
+							cnt -= rp[row + 1] - rp[row];
+				w[(size_t) c] = std::make_pair(-cnt, (int) c);
+			}
+			std::sort(w.begin(), w.end());
+			// min-heap of (entries so far, workgroup); a workgroup that holds cap_chunks chunks leaves it
+			std::vector<std::pair<long, int>> heap;
+			for (int j = 0; j < WGS; j++)
+				heap.emplace_back(0L, j);
+			auto cmp = [](const std::pair<long, int> & p, const std::pair<long, int> & q) { return p > q; };
+			std::make_heap(heap.begin(), heap.end(), cmp);
+			for (const auto & c : w)
+			{
+				std::pop_heap(heap.begin(), heap.end(), cmp);
+				std::pair<long, int> top = heap.back();
+				heap.pop_back();
+				std::vector<int> & lst = mine[(size_t) (r * WGS + top.second)];
+				lst.push_back(c.second);
+				top.first += -c.first;
+				if ((long) lst.size() < cap_chunks)
 				{
-					int lo = 0x7fffffff, hi = -1;
-					for (long e = e0; e < e1; e++)
-					{
-						lo = std::min(lo, ci[e]);
-						hi = std::max(hi, ci[e]);
-					}
-					for (long b = lo / W; b <= hi / W; b++)
-						bs.push_back((int) (b * W));
-					continue;
-				}
-				hist.assign((size_t) n, 0);
-				for (long e = e0; e < e1; e++)
-					hist[(size_t) ci[e]]++;
-				long start = -1, acc = 0;
-				for (long c = 0; c < n; c++)
-				{
-					const long h = hist[(size_t) c];
-					if (h == 0)
-						continue;
-					if (start < 0 || c - start >= 65536 || (acc > 0 && acc + h > target))
-					{
-						bs.push_back((int) c);
-						start = c;
-						acc = 0;
-					}
-					acc += h;
+					heap.push_back(top);
+					std::push_heap(heap.begin(), heap.end(), cmp);
 				}
 			}
+			for (int j = 0; j < WGS; j++)
+				std::sort(mine[(size_t) (r * WGS + j)].begin(), mine[(size_t) (r * WGS + j)].end());
 		}
+		for (long t = 0; t < NT; t++)
+			chunk_ptr[(size_t) t + 1] = chunk_ptr[(size_t) t] + (int) mine[(size_t) t].size();
+		chunk_row.resize((size_t) chunk_ptr[(size_t) NT] + 1, 0);
+		for (long t = 0; t < NT; t++)
+			for (size_t k = 0; k < mine[(size_t) t].size(); k++)
+				chunk_row[(size_t) chunk_ptr[(size_t) t] + k] = (int) (range_row[t / WGS] + (long) mine[(size_t) t][k] * CH);
 	}
-	long B = 1;
-	for (long r = 0; r < NR; r++)
-		B = std::max<long>(B, (long) bstart[(size_t) r].size());
-	if (B > 65536)
-	{
-		set_error("col_blocks: %ld column blocks in one row range (limit 65536)", B);
-		return 1;
-	}
-	// block of column c in range r: the last block starting at or before c
-	auto block_of = [&](long r, int c) {
-		const std::vector<int> & bs = bstart[(size_t) r];
-		return (long) (std::upper_bound(bs.begin(), bs.end(), c) - bs.begin()) - 1;
-	};
-	// ---- entries of every workgroup: offsets first (workgroups in order), then fill + sort
+	// ---- entries of every workgroup: (column, LDS slot[, value]) sorted by column, cut into batches of BATCH entries. A batch has a
+	// base column (its first entry's) and holds entries whose column - base fits SPAN (17 bits, or ceil(n / col_blocks) columns when
+	// col_blocks > 0); what is left of a batch is padding: column offset 0, a spare LDS slot, value 0.
+	const int SLOT_BITS = coo_blocked_slot_bits(), SPARE = coo_blocked_spare_slots();
+	const long BATCH = coo_blocked_batch_entries(uniform);
+	const long NW = 1024 / 64, KPL = BATCH / 1024;                 // waves per workgroup, entries per lane and batch
+	const long SPAN = col_blocks > 0 ? std::max<long>(1, std::min<long>((n + col_blocks - 1) / col_blocks, 1L << (32 - SLOT_BITS))) : 1L << (32 - SLOT_BITS);
 	std::vector<int> wg_rows((size_t) NT, 0);
-	std::vector<long> wg_nnz((size_t) NT + 1, 0);
-	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 8)
-	for (long t = 0; t < NT; t++)
+	struct Ent { unsigned long long key; double v; };
+	std::vector<std::vector<unsigned>> wg_ent((size_t) NT);
+	std::vector<std::vector<double>> wg_val((size_t) NT);
+	std::vector<std::vector<int>> wg_base((size_t) NT);
+	long placed = 0;
+	#pragma omp parallel num_threads(spmv::host_threads()) reduction(+ : placed)
 	{
-		const long r = t / WGS, j = t % WGS;
-		const long r0 = range_row[r], r1 = range_row[r + 1];
-		const long chunks = (r1 - r0 + CH - 1) / CH;
-		const long mine = chunks > j ? (chunks - j + WGS - 1) / WGS : 0;
-		const long nlong = range_long[r + 1] - range_long[r];
-		wg_rows[t] = (int) (mine * CH + nlong);
-		long cnt = 0;
-		for (long c = j; c < chunks; c += WGS)
-		{
-			const long a = r0 + c * CH, b = std::min(r1, a + CH);
-			cnt += rp[b] - rp[a];
-			if (nlong)
-				for (long row = a; row < b; row++)
-					if (is_long(r, row))
-						cnt -= rp[row + 1] - rp[row];
-		}
-		for (long k = range_long[r]; k < range_long[r + 1]; k++)
-		{
-			long a, b;
-			piece(long_row[(size_t) k], j, a, b);
-			cnt += b - a;
-		}
-		wg_nnz[t + 1] = cnt;
-	}
-	for (long t = 0; t < NT; t++)
-		wg_nnz[t + 1] += wg_nnz[t];
-	std::vector<int> seg_blk((size_t) NT * (B + 1), 0);
-	std::vector<unsigned> ent((size_t) std::max<long>(lnnz, 1));
-	std::vector<double> pval(uniform ? 0 : (size_t) std::max<long>(lnnz, 1));
-	#pragma omp parallel num_threads(spmv::host_threads())
-	{
-		std::vector<int> pos((size_t) B + 1);
-		std::vector<std::pair<unsigned, double>> tmp;
+		std::vector<Ent> tmp;
 		#pragma omp for schedule(dynamic, 4)
 		for (long t = 0; t < NT; t++)
 		{
 			const long r = t / WGS, j = t % WGS;
-			const long r0 = range_row[r], r1 = range_row[r + 1];
-			const long chunks = (r1 - r0 + CH - 1) / CH;
-			const long mine = chunks > j ? (chunks - j + WGS - 1) / WGS : 0;
+			const long r1 = range_row[r + 1];
+			const long mine = chunk_ptr[(size_t) t + 1] - chunk_ptr[(size_t) t];
+			const int * cr = chunk_row.data() + chunk_ptr[(size_t) t];
 			const long nlong = range_long[r + 1] - range_long[r];
-			int * sb = seg_blk.data() + (size_t) t * (B + 1);
+			wg_rows[(size_t) t] = (int) (mine * CH + nlong);
+			const unsigned spare0 = (unsigned) (mine * CH + nlong);          // first spare slot
 			// the workgroup's entries as (first, last, LDS slot) spans: its chunk rows, then its pieces of the split rows
-			auto for_each_span = [&](auto && fn) {
-				for (long c = j; c < chunks; c += WGS)
-				{
-					const long a = r0 + c * CH, bnd = std::min(r1, a + CH);
-					for (long row = a; row < bnd; row++)
-						if (!(nlong && is_long(r, row)))
-							fn((long) rp[row], (long) rp[row + 1], (unsigned) ((c / WGS) * CH + (row - a)));
-				}
-				for (long k = 0; k < nlong; k++)
-				{
-					long a, b;
-					piece(long_row[(size_t) (range_long[r] + k)], j, a, b);
-					fn(a, b, (unsigned) (mine * CH + k));
-				}
+			tmp.clear();
+			auto span = [&](long a, long b, unsigned slot) {
+				for (long e = a; e < b; e++)
+					tmp.push_back(Ent{((unsigned long long) (unsigned) ci[e] << 32) | slot, uniform ? 0.0 : va[e]});
 			};
-			std::fill(pos.begin(), pos.end(), 0);
-			for_each_span([&](long a, long b, unsigned) {
-				for (long e = a; e < b; e++)
-					pos[(size_t) block_of(r, ci[e]) + 1]++;
-			});
-			sb[0] = (int) wg_nnz[t];
-			for (long b = 0; b < B; b++)
-				sb[b + 1] = sb[b] + pos[(size_t) b + 1];
-			for (long b = 0; b <= B; b++)
-				pos[(size_t) b] = sb[b];
-			for_each_span([&](long a, long b, unsigned l) {
-				for (long e = a; e < b; e++)
-				{
-					const long blk = block_of(r, ci[e]);
-					const int at = pos[(size_t) blk]++;
-					ent[(size_t) at] = ((unsigned) (ci[e] - bstart[(size_t) r][(size_t) blk]) << 16) | l;
-					if (!uniform)
-						pval[(size_t) at] = va[e];
-				}
-			});
-			// inside a block: by column, then LDS slot (the packed dword is that key)
-			for (long b = 0; b < B; b++)
+			for (long c = 0; c < mine; c++)
 			{
-				const int s0 = sb[b], s1 = sb[b + 1];
-				if (s1 - s0 < 2)
-					continue;
-				if (uniform)
-					std::sort(ent.begin() + s0, ent.begin() + s1);
-				else
+				const long a = cr[c], bnd = std::min(r1, a + CH);
+				for (long row = a; row < bnd; row++)
+					if (!(nlong && is_long(r, row)))
+						span((long) rp[row], (long) rp[row + 1], (unsigned) (c * CH + (row - a)));
+			}
+			for (long k = 0; k < nlong; k++)
+			{
+				long a, b;
+				piece(long_row[(size_t) (range_long[r] + k)], j, a, b);
+				span(a, b, (unsigned) (mine * CH + k));
+			}
+			placed += (long) tmp.size();
+			std::stable_sort(tmp.begin(), tmp.end(), [](const Ent & p, const Ent & q) { return p.key < q.key; });
+			std::vector<unsigned> & E = wg_ent[(size_t) t];
+			std::vector<double> & V = wg_val[(size_t) t];
+			std::vector<int> & Bs = wg_base[(size_t) t];
+			// position p of a batch is entry u = p / 1024 of lane p % 1024: the 64 entries of one wave instruction are 64 consecutive
+			// positions, and the instructions of a batch in sorted order are (u, wave) = (0, 0), (0, 1), ... (0, 15), (1, 0), ...
+			// Every instruction has its own base column (table [batch][wave][u]) and takes sorted entries while column - base < SPAN.
+			size_t k = 0;
+			long lastbase = 0;
+			while (k < tmp.size())
+			{
+				const size_t b0 = Bs.size();
+				Bs.resize(b0 + (size_t) (NW * KPL), 0);
+				for (long g = 0; g < NW * KPL; g++)
 				{
-					tmp.resize((size_t) (s1 - s0));
-					for (int k = s0; k < s1; k++)
-						tmp[(size_t) (k - s0)] = std::make_pair(ent[(size_t) k], pval[(size_t) k]);
-					std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<unsigned, double> & p, const std::pair<unsigned, double> & q) { return p.first < q.first; });
-					for (int k = s0; k < s1; k++)
+					const long u = g / NW, w = g % NW;
+					const long base = k < tmp.size() ? (long) (tmp[k].key >> 32) : lastbase;
+					lastbase = base;
+					Bs[b0 + (size_t) (w * KPL + u)] = (int) base;
+					long fill = 0;
+					for (; fill < 64 && k < tmp.size() && (long) (tmp[k].key >> 32) - base < SPAN; fill++, k++)
 					{
-						ent[(size_t) k] = tmp[(size_t) (k - s0)].first;
-						pval[(size_t) k] = tmp[(size_t) (k - s0)].second;
+						E.push_back((unsigned) (((long) (tmp[k].key >> 32) - base) << SLOT_BITS) | (unsigned) (tmp[k].key & 0xffffffffu));
+						if (!uniform)
+							V.push_back(tmp[k].v);
 					}
+					for (; fill < 64; fill++)
+					{
+						E.push_back(spare0 + (unsigned) (fill % SPARE));
+						if (!uniform)
+							V.push_back(0.0);
+					}
+				}
+			}
+			// the kernel's loop is unrolled over three rotating register sets: whole batches of padding up to a multiple of 3
+			while ((Bs.size() / (size_t) (NW * KPL)) % 3)
+			{
+				const int last = Bs.back();
+				Bs.resize(Bs.size() + (size_t) (NW * KPL), last);
+				for (long fill = 0; fill < BATCH; fill++)
+				{
+					E.push_back(spare0 + (unsigned) (fill % SPARE));
+					if (!uniform)
+						V.push_back(0.0);
 				}
 			}
 		}
 	}
-	if (wg_nnz[NT] != lnnz)
+	if (placed != lnnz)
 	{
-		set_error("column-blocked layout: %ld entries placed, %ld expected", wg_nnz[NT], lnnz);
+		set_error("column-blocked layout: %ld entries placed, %ld expected", placed, lnnz);
 		return 1;
 	}
-	// ---- per range: number of blocks, then the first column of every block
-	std::vector<int> range_blk((size_t) NR * (B + 1), 0);
+	std::vector<int> batch_ptr((size_t) NT + 1, 0);
 	int max_rows = 0;
-	for (long r = 0; r < NR; r++)
+	for (long t = 0; t < NT; t++)
 	{
-		const std::vector<int> & bs = bstart[(size_t) r];
-		range_blk[(size_t) r * (B + 1)] = (int) bs.size();
-		for (size_t b = 0; b < bs.size(); b++)
-			range_blk[(size_t) r * (B + 1) + 1 + b] = bs[b];
-		for (long t = r * WGS; t < (r + 1) * WGS; t++)
-			max_rows = std::max(max_rows, wg_rows[(size_t) t]);
+		batch_ptr[(size_t) t + 1] = batch_ptr[(size_t) t] + (int) (wg_base[(size_t) t].size() / (size_t) (NW * KPL));
+		max_rows = std::max(max_rows, wg_rows[(size_t) t]);
 	}
+	const long NB = batch_ptr[(size_t) NT];
+	if (getenv("SPMV_MI355X_COOB_DEBUG"))
+		for (long r = 0; r < NR; r++)
+		{
+			long mn = 1L << 40, mx = 0, sum = 0, ent_r = rp[range_row[r + 1]] - rp[range_row[r]];
+			for (long t = r * WGS; t < (r + 1) * WGS; t++)
+			{
+				const long b = batch_ptr[(size_t) t + 1] - batch_ptr[(size_t) t];
+				mn = std::min(mn, b), mx = std::max(mx, b), sum += b;
+			}
+			fprintf(stderr, "coob range %ld: rows %d..%d, %ld entries, %d split rows, batches per workgroup min %ld mean %.1f max %ld, fill %.3f, rows per workgroup %d..%d\n", r,
+					range_row[r], range_row[r + 1], ent_r, range_long[r + 1] - range_long[r], mn, (double) sum / WGS, mx, (double) ent_r / ((double) sum * BATCH),
+					*std::min_element(wg_rows.begin() + r * WGS, wg_rows.begin() + (r + 1) * WGS), *std::max_element(wg_rows.begin() + r * WGS, wg_rows.begin() + (r + 1) * WGS));
+		}
+	// the kernel loads entries and base columns two batches ahead without clamping: two all-zero batches behind the last
+	const long GHOST = 2;
+	std::vector<int> batch_base((size_t) ((NB + GHOST) * NW * KPL), 0);
+	std::vector<unsigned> ent((size_t) ((NB + GHOST) * BATCH), 0u);
+	std::vector<double> pval(uniform ? 0 : (size_t) ((NB + GHOST) * BATCH), 0.0);
+	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4)
+	for (long t = 0; t < NT; t++)
+	{
+		const size_t b0 = (size_t) batch_ptr[(size_t) t];
+		std::copy(wg_base[(size_t) t].begin(), wg_base[(size_t) t].end(), batch_base.begin() + b0 * (size_t) (NW * KPL));
+		std::copy(wg_ent[(size_t) t].begin(), wg_ent[(size_t) t].end(), ent.begin() + b0 * BATCH);
+		if (!uniform)
+			std::copy(wg_val[(size_t) t].begin(), wg_val[(size_t) t].end(), pval.begin() + b0 * BATCH);
+		std::vector<unsigned>().swap(wg_ent[(size_t) t]);
+		std::vector<double>().swap(wg_val[(size_t) t]);
+	}
+	const long lext = (NB + GHOST) * BATCH;        // stored entries, padding and the two ghost batches included
 	if (upload_ints(wg_rows.data(), wg_rows.size(), &A->d_coob_wg_rows) || upload_ints(range_row.data(), range_row.size(), &A->d_coob_range_row) ||
-	    upload_ints(seg_blk.data(), seg_blk.size(), &A->d_coob_seg_blk) || upload_ints(range_blk.data(), range_blk.size(), &A->d_coob_range_blk) ||
+	    upload_ints(chunk_ptr.data(), chunk_ptr.size(), &A->d_coob_chunk_ptr) || upload_ints(chunk_row.data(), chunk_row.size(), &A->d_coob_chunk_row) ||
+	    upload_ints(batch_ptr.data(), batch_ptr.size(), &A->d_coob_batch_ptr) || upload_ints(batch_base.data(), batch_base.size(), &A->d_coob_batch_base) ||
 	    upload_ints(range_long.data(), range_long.size(), &A->d_coob_range_long) || upload_ints(long_row.data(), long_row.size(), &A->d_coob_long_row) ||
 	    dev_alloc_bytes(&A->d_coob_carry, (size_t) std::max<long>(NL, 1) * WGS * A->vbytes) ||
-	    upload_bytes(ent.data(), (size_t) lnnz * 4, (size_t) coo_blocked_entry_slack() * 4, (void **) &A->d_coob_ent))
+	    upload_bytes(ent.data(), (size_t) lext * 4, 64, (void **) &A->d_coob_ent))
 		return 1;
 	if (!uniform)
 	{
-		// narrowed values with the same slack as the entries (the kernel's loads are unconditional)
-		const size_t slack = (size_t) coo_blocked_entry_slack() * A->vbytes;
 		if (A->f32)
 		{
-			std::vector<float> pf32((size_t) std::max<long>(lnnz, 1));
+			std::vector<float> pf32((size_t) std::max<long>(lext, 1));
 			#pragma omp parallel for num_threads(spmv::host_threads())
-			for (long e = 0; e < lnnz; e++)
+			for (long e = 0; e < lext; e++)
 				pf32[(size_t) e] = (float) pval[(size_t) e];
-			if (upload_bytes(pf32.data(), (size_t) lnnz * 4, slack, &A->d_val))
+			if (upload_bytes(pf32.data(), (size_t) lext * 4, 64, &A->d_val))
 				return 1;
 		}
-		else if (upload_bytes(pval.data(), (size_t) lnnz * 8, slack, &A->d_val))
+		else if (upload_bytes(pval.data(), (size_t) lext * 8, 64, &A->d_val))
 			return 1;
 	}
 	if (uniform)
@@ -317,14 +325,14 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 		A->cfg.unit_value = v0;
 	}
 	A->coob_ranges = (int) NR;
-	A->coob_blocks = (int) B;
-	A->coob_block_cols = (int) CH;                // rows per chunk of the deal (the field's second life)
+	A->coob_batches = NB;
+	A->coob_chunk_rows = (int) CH;
 	A->coob_num_long = (int) NL;
-	A->coob_lds = (int) (((long) std::max(max_rows, 1) * 8 + 15) / 16 * 16);      // fp64 slots for both precisions
+	A->coob_lds = (int) (((long) (std::max(max_rows, 1) + SPARE) * 8 + 15) / 16 * 16);      // fp64 slots for both precisions
 	A->cfg.map = xcd_map_uniform(1, 0);
-	A->mem_footprint = (double) lnnz * (4 + (uniform ? 0 : A->vbytes)) + (double) NT * (B + 2) * 4 + (double) NR * (B + 4) * 4 + NL * (4.0 + WGS * A->vbytes);
-	snprintf(A->format_name, sizeof(A->format_name), "MI355X_%s_r%ld_%s%ld%s%s_%s", merge_balance ? "MERGEB" : "COOB", NR, col_blocks > 0 ? "b" : "e", B, NL ? "_split" : "",
-			uniform ? "_unit" : "", pf);
+	A->mem_footprint = (double) lext * (4 + (uniform ? 0 : A->vbytes)) + (double) (NT + 1) * 4 + (double) NB * NW * KPL * 4 + (double) NT * 8 + (double) chunk_row.size() * 4 + (double) NR * 8 + NL * (4.0 + WGS * A->vbytes);
+	snprintf(A->format_name, sizeof(A->format_name), "MI355X_%s_r%ld_k%ld_%s%ld%s%s_%s", merge_balance ? "MERGEB" : "COOB", NR, BATCH / 1024, col_blocks > 0 ? "w" : "b",
+			col_blocks > 0 ? SPAN : NB, NL ? "_split" : "", uniform ? "_unit" : "", pf);
 	snprintf(A->kernel_name, sizeof(A->kernel_name), "coo_blocked_kernel");
 	A->kernel_block = 1024;
 	return 0;

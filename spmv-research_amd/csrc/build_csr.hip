@@ -287,34 +287,13 @@ build_csr_merge(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const double
 	return rc;
 }
 
-// Would the x gathers of this matrix miss the XCD's L2 if the entries were consumed in CSR order? x larger than two L2s and,
-// on a sample of rows, most entries more than a 4 KiB page of x away from their predecessor in the row (graph matrices; a
-// stencil / FEM row is a few runs of neighbouring columns).
-static bool
-gathers_scattered(const spmv_mi355x_matrix * A, const int * rp, const int * ci)
-{
-	const long lm = A->m;
-	if ((double) A->n * A->vbytes <= 8.0 * 1024 * 1024 || A->nnz < (1L << 22))
-		return false;
-	const long page = 4096 / (long) A->vbytes;
-	long far = 0, seen = 0;
-	const long stride = std::max<long>(1, lm / 4096);
-	for (long i = 0; i < lm; i += stride)
-		for (long j = rp[i] + 1; j < rp[i + 1]; j++)
-		{
-			seen++;
-			far += (long) ci[j] - ci[j - 1] > page;
-		}
-	return seen > 0 && 2 * far > seen;
-}
-
 int
 build_csr_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * rp, const int * ci, const double * va)
 {
 	const long lm = A->m, lnnz = A->nnz;
-	// merge path on a matrix whose gathers are scattered over an x that no L2 holds: the merge-balanced column-blocked layout
-	// (kernels_coo.hip). col_blocks: 0 = auto, -1 / > 0 = blocked, -2 = plain CSR-order merge path
-	if (A->format == SPMV_MI355X_CSR_MERGE && o.col_blocks != -2 && (o.col_blocks != 0 || gathers_scattered(A, rp, ci)))
+	// merge path: col_blocks = 0 (default) / -2 = the CSR-order merge path (merge.cpp:256-319: deterministic sums); -1 / > 0 = the
+	// merge-balanced column-blocked layout (kernels_coo.hip: LDS atomics, sums to tolerance) — only when the caller asks for it
+	if (A->format == SPMV_MI355X_CSR_MERGE && (o.col_blocks == -1 || o.col_blocks > 0))
 		return build_blocked_layout(A, rp, ci, va, o.col_blocks, true);
 	if (upload_ints(rp, (size_t) lm + 1, &A->d_row_ptr) || upload_ints(ci, (size_t) lnnz, &A->d_col) ||
 	    upload_values(A, va, (size_t) lnnz, &A->d_val))

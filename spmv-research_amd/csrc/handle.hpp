@@ -40,16 +40,19 @@ struct spmv_mi355x_matrix {
 	int * d_coords = nullptr;
 	int * d_carry_row = nullptr;
 	void * d_carry_val = nullptr;
-	// column-blocked COO (opts.col_blocks; kernels_coo.hip): 8*P row ranges, 32 workgroups per range, entries by column block
+	// column-blocked COO (opts.col_blocks; kernels_coo.hip): 8*P row ranges, 32 workgroups per range, entries sorted by column in full batches
 	int * d_coob_wg_rows = nullptr;        // [ranges*32] rows of y a workgroup keeps in LDS
 	int * d_coob_range_row = nullptr;      // [ranges+1]
-	int * d_coob_seg_blk = nullptr;        // [ranges*32][blocks+1] entry offsets per workgroup and column block
-	int * d_coob_range_blk = nullptr;      // [ranges][2] column blocks a range's workgroups walk
-	unsigned * d_coob_ent = nullptr;       // [nnz] column in block << 16 | row in workgroup
+	int * d_coob_chunk_ptr = nullptr;      // [ranges*32+1] first chunk of every workgroup
+	int * d_coob_chunk_row = nullptr;      // [chunks] first row of a chunk of 16 rows
+	int * d_coob_batch_ptr = nullptr;      // [ranges*32+1] first batch of every workgroup
+	int * d_coob_batch_base = nullptr;     // [batches] base column of a batch
+	unsigned * d_coob_ent = nullptr;       // [batches * K * 1024] (column - base) << 15 | LDS slot of the row
 	int * d_coob_range_long = nullptr;     // [ranges+1] prefix of the split (hub) rows per range
 	int * d_coob_long_row = nullptr;       // [num_long] their global row numbers
 	void * d_coob_carry = nullptr;         // [num_long][32] partial sums of the split rows
-	int coob_ranges = 0, coob_blocks = 0, coob_block_cols = 0, coob_lds = 0, coob_num_long = 0;
+	int coob_ranges = 0, coob_chunk_rows = 0, coob_lds = 0, coob_num_long = 0;
+	long coob_batches = 0;
 	// SELL
 	int sell_c = 0;
 	long sell_sigma = 0, sell_slices = 0, sell_nnz_ext = 0;

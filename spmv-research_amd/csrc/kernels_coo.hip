@@ -187,111 +187,93 @@ launch_coo(bool f32, int items_per_lane, const int * rowind, const int * col, co
 // ------------------------------------------------------------------------------------------------ column-blocked COO
 //
 // For graph matrices (soc-LiveJournal1: 14 entries per row scattered over a 39 MB x) the row-sorted kernels sit on the
-// fabric's random-sector rate: every gather misses the 4 MiB L2 of its XCD and most of the 64 bytes it brings are unused.
+// fabric's random-sector rate: every gather misses the 4 MiB L2 of its XCD and most of the bytes it brings are unused.
 // MI355X has 160 KiB of LDS on each of its 256 CUs — 40 MiB in all, as much as the whole y of such a matrix — and eight L2s
 // that each serve 32 CUs. The layout below is built around both:
 //   * the rows are cut into 8*P contiguous RANGES (P = 1 while y fits the chip's LDS); XCD k owns ranges k*P .. k*P+P-1 and
 //     works through them one after the other;
-//   * a range is dealt to 32 workgroups (one per CU, 1024 threads) in chunks of 16 rows, round-robin: every workgroup of the
-//     range sees the same column structure and the same number of entries per column block, and its y rows (<= 160 KiB)
-//     live in LDS for the whole launch, written back once as full 128-byte lines;
-//   * a workgroup's entries are ordered by column block (<= 65 536 columns of x, default 384 KiB) and, inside a block, by
-//     column: the 32 workgroups of an XCD sweep the same block at the same time, so the block is fetched into that L2 once,
-//     and neighbouring lanes gather from neighbouring lines (several entries per 128-byte line instead of one);
-//   * an entry is ONE dword: column inside the block (16 bits) | row inside the workgroup (16 bits), + the value unless all
-//     values are equal (Matrix-Market `pattern` matrices): 4 bytes per non-zero of stream instead of CSR's 12;
-//   * v*x[col] is added into the LDS copy of y with ds_add (LDS atomics): the order of a row's additions is run-dependent,
-//     parity is to the tolerance (1e-12 / 1e-5), not bit-wise.
+//   * a range is dealt to 32 workgroups (one per CU, 1024 threads) in chunks of 16 rows so that every workgroup gets the same
+//     number of entries (longest chunk first to the emptiest workgroup): every workgroup of the range sees the same column
+//     structure, and its y rows (<= 160 KiB) live in LDS for the whole launch, written back once as full 128-byte lines;
+//   * a workgroup's entries are sorted by COLUMN and cut into BATCHES of K x 1024 (K entries per lane: 8 for pattern matrices,
+//     4 with a value stream). The 64 entries one wave instruction gathers have a base column (a wave-uniform scalar: 16 x K
+//     per batch); an entry is ONE dword: column - base (17 bits) | LDS slot of its row (15 bits), + the value unless all values
+//     are equal (Matrix-Market `pattern` matrices): 4 bytes per non-zero of stream instead of CSR's 12. Every batch is full (the
+//     last one is padded with entries that add into spare LDS slots; so is an instruction whose 64 sorted entries would span more
+//     than 2^17 columns), so the loop below has no branch around any load: the compiler counts the outstanding memory operations
+//     exactly. The 32 workgroups of an XCD sweep the same columns at about the same time, so that stretch of x enters the XCD's
+//     L2 once; neighbouring lanes gather from neighbouring lines;
+//   * v*x[col] is added into the LDS copy of y with ds_add_f64 (LDS atomics): the order of a row's additions is run-dependent,
+//     parity is to the tolerance (1e-12 / 1e-5), not bit-wise;
 //   * a row too long for one workgroup's share (a hub of a power-law graph) is SPLIT over the 32 workgroups of its range, each
 //     summing a contiguous piece into an extra LDS slot; the 32 partial sums go to a carry array and a fix-up kernel adds
 //     them to y in workgroup order — the merge-path remedy (merge.cpp:302-318: partial rows + carry fix-up) inside this layout.
-// The next block's first batch of entries is in flight while the current block is consumed; a workgroup barrier after
-// every block keeps the 16 waves on the same block of x.
+//
+// What bounds it (tools/gather_bench*.hip, profiles/r03_gather_bench*.txt): a CU takes in one 128-byte line of x per ~2 clocks
+// (64 B/clk, L2-served) whatever part of the line is used, + ~0.2 clk per gathering lane; the twin touches 0.44 distinct lines per
+// entry and workgroup -> ~1.28 clk per entry = 165 us for 69 M entries; ds_add_f64 costs 0.44 clk per entry and runs in the LDS
+// pipeline BESIDE the gathers if the gathers of batch i+1 are issued before the adds of batch i: the loop is rotated by hand over
+// three entry buffers and three gather buffers (period 3) so that no register copy puts a wait between them. (Round 2's loop had a
+// branch around every gather and the compiler put `s_waitcnt vmcnt(0)` after each: 250 us.)
 constexpr int COOB_THREADS = 1024;
-constexpr int COOB_U = 8;                  // entries per lane and batch
 constexpr int COOB_WGS = 32;               // workgroups per range = CUs per XCD
 constexpr int COOB_CHUNK = 16;             // rows per chunk of the round-robin deal
+constexpr int COOB_SLOT_BITS = 15;         // LDS slot of the entry's row (a workgroup holds at most 20 480 fp64 slots)
+constexpr int COOB_SPARE = 64;             // spare LDS slots the padding entries add into (one per lane of a wave: no conflicts)
+constexpr unsigned COOB_SLOT_MASK = (1u << COOB_SLOT_BITS) - 1;
 
-template <typename T, bool UNIT>
+template <typename T, bool UNIT, int K>
 struct CoobBatch {
-	unsigned e[COOB_U];
-	T v[UNIT ? 1 : COOB_U];
+	unsigned e[K];
+	T v[UNIT ? 1 : K];
 };
 
-// Branch-free: the entry arrays carry COOB_SLACK spare entries, so a lane past the end of its block loads something valid and
-// discards it. Straight-line loads let the compiler count the outstanding memory operations exactly (s_waitcnt vmcnt(N));
-// with a branch around every load it fell back to vmcnt(0) before each gather and the prefetch below was waited for at once.
-template <typename T, bool UNIT>
+// the entry streams are read once: nontemporal, so that they do not push x out of L2
+template <typename T, bool UNIT, int K>
 __device__ __forceinline__ void
-coob_load(CoobBatch<T, UNIT> & b, const unsigned * __restrict__ ent, const T * __restrict__ val, int first)
+coob_load(CoobBatch<T, UNIT, K> & b, const unsigned * __restrict__ ent, const T * __restrict__ val, size_t first)
 {
 	#pragma unroll
-	for (int u = 0; u < COOB_U; u++)
+	for (int u = 0; u < K; u++)
 	{
-		// the entry streams are read once: nontemporal, so that they do not push the x block out of L2
-		b.e[u] = ld_stream<true>(ent + first + u * COOB_THREADS);
+		b.e[u] = ld_stream<true>(ent + first + (size_t) u * COOB_THREADS);
 		if constexpr (!UNIT)
-			b.v[u] = ld_stream<true>(val + first + u * COOB_THREADS);
+			b.v[u] = ld_stream<true>(val + first + (size_t) u * COOB_THREADS);
 	}
 }
 
-// Lanes past the end of the block issue NO gather: the vector memory pipeline handles a gather lane by lane (PMC: one L1
-// access per lane), and dummy gathers for the idle lanes cost 316 instead of 244 us on the soc-LiveJournal1 twin.
-template <typename T, bool UNIT>
+// base: the K base columns of this wave's K instructions of the batch (wave-uniform: scalar loads, scalar x pointers)
+template <typename T, bool UNIT, int K>
 __device__ __forceinline__ void
-coob_gather(T (&xv)[COOB_U], const CoobBatch<T, UNIT> & b, const T * __restrict__ xb, int first, int end)
+coob_gather(T (&xv)[K], const CoobBatch<T, UNIT, K> & b, const T * __restrict__ x, const int * __restrict__ base)
 {
 	#pragma unroll
-	for (int u = 0; u < COOB_U; u++)
-	{
-		xv[u] = 0;
-		if (first + u * COOB_THREADS < end)
-			xv[u] = xb[b.e[u] >> 16];
-	}
+	for (int u = 0; u < K; u++)
+		xv[u] = (x + base[u])[b.e[u] >> COOB_SLOT_BITS];
 }
 
-// The LDS copy of y is fp64 for both precisions: ds_add_f32 runs at half the rate of ds_add_f64 on this part (fp32 on the
-// soc-LiveJournal1 twin: 487 us with float atomics, 259 us with plain stores in their place), and the sums are more accurate.
-template <typename T, bool UNIT>
+// The LDS copy of y is fp64 for both precisions: ds_add_f32 runs at a sixth of the rate of ds_add_f64 on this part (2.7 against
+// 0.44 clocks per entry and CU, profiles/r03_gather_bench2.txt), and the sums are more accurate.
+template <typename T, bool UNIT, int K>
 __device__ __forceinline__ void
-coob_add(const T (&xv)[COOB_U], const CoobBatch<T, UNIT> & b, double * __restrict__ ys, T unit, int first, int end)
+coob_add(const T (&xv)[K], const CoobBatch<T, UNIT, K> & b, double * __restrict__ ys, T unit)
 {
 	#pragma unroll
-	for (int u = 0; u < COOB_U; u++)
-		if (first + u * COOB_THREADS < end)
-			unsafeAtomicAdd(&ys[b.e[u] & 0xffffu], (double) (UNIT ? unit : b.v[u]) * (double) xv[u]);
+	for (int u = 0; u < K; u++)
+		unsafeAtomicAdd(&ys[b.e[u] & COOB_SLOT_MASK], (double) (UNIT ? unit : b.v[u]) * (double) xv[u]);
 }
 
-// One column block of one workgroup: gathers of the current batch first, THEN the prefetch of the batch two blocks ahead
-// (vector memory operations complete in issue order: everything issued before the gathers would have to land before they do),
-// then the LDS adds, then whatever the block holds beyond one batch.
-template <typename T, bool UNIT>
-__device__ __forceinline__ void
-coob_step(const CoobBatch<T, UNIT> & cur, CoobBatch<T, UNIT> & pf, const unsigned * __restrict__ ent, const T * __restrict__ val,
-		const T * __restrict__ xb, double * __restrict__ ys, T unit, int e0, int e1, int pf_first, int tid)
-{
-	T xv[COOB_U];
-	coob_gather<T, UNIT>(xv, cur, xb, e0 + tid, e1);
-	coob_load<T, UNIT>(pf, ent, val, pf_first + tid);
-	coob_add<T, UNIT>(xv, cur, ys, unit, e0 + tid, e1);
-	for (int e = e0 + tid + COOB_U * COOB_THREADS; e < e1; e += COOB_U * COOB_THREADS)
-	{
-		CoobBatch<T, UNIT> more;
-		coob_load<T, UNIT>(more, ent, val, e);
-		coob_gather<T, UNIT>(xv, more, xb, e, e1);
-		coob_add<T, UNIT>(xv, more, ys, unit, e, e1);
-	}
-}
-
-template <typename T, bool UNIT>
+template <typename T, bool UNIT, int K>
 __global__ __launch_bounds__(COOB_THREADS) void
-coo_blocked_kernel(const int * __restrict__ wg_rows, const int * __restrict__ range_row, const int * __restrict__ seg_blk,
-		const int * __restrict__ range_blk, const int * __restrict__ range_long, const unsigned * __restrict__ ent,
+coo_blocked_kernel(const int * __restrict__ wg_rows, const int * __restrict__ range_row, const int * __restrict__ chunk_ptr,
+		const int * __restrict__ chunk_row, const int * __restrict__ batch_ptr,
+		const int * __restrict__ batch_base, const int * __restrict__ range_long, const unsigned * __restrict__ ent,
 		const T * __restrict__ val, const T * __restrict__ x, T * __restrict__ y, T * __restrict__ carry,
-		int ranges_per_xcd, int max_blocks, int chunk_rows, int sync_every, T unit, int beta)
+		int ranges_per_xcd, int chunk_rows, int sync_mask, T unit, int beta)
 {
 	extern __shared__ __align__(16) unsigned char coob_smem[];
 	double * ys = reinterpret_cast<double *>(coob_smem);
+	constexpr size_t BATCH = (size_t) K * COOB_THREADS;
 	// workgroups are dealt round-robin to the XCDs: the i-th workgroup of XCD k is the (i % 32)-th of its (i / 32)-th range
 	const int xcd = (int) blockIdx.x % NUM_XCD;
 	const int i = (int) blockIdx.x / NUM_XCD;
@@ -302,51 +284,60 @@ coo_blocked_kernel(const int * __restrict__ wg_rows, const int * __restrict__ ra
 	if (nloc == 0)
 		return;                            // whole workgroup: no rows, hence no entries
 	const int tid = (int) threadIdx.x;
-	for (int l = tid; l < nloc; l += COOB_THREADS)
+	for (int l = tid; l < nloc + COOB_SPARE; l += COOB_THREADS)
 		ys[l] = 0;
-	const int * sb = seg_blk + (size_t) t * (max_blocks + 1);
-	const int * bc = range_blk + (size_t) range * (max_blocks + 1);        // [0] = blocks of this range, [1 + b] = first column of block b
-	const int b0 = 0, b1 = bc[0];
-	auto xblk = [&](int b) { return x + bc[1 + (b < b1 ? b : b1 - 1)]; };
-	// entry offset of block b, clamped to the last boundary (blocks past the range's last hold nothing)
-	auto at = [&](int b) { return sb[b < b1 ? b : b1]; };
-	CoobBatch<T, UNIT> q0, q1, q2;
-	if (b0 < b1)
+	const int nb = batch_ptr[t + 1] - batch_ptr[t];
+	// base columns: [batch][wave][K]; the wave number is uniform, said so to the compiler for scalar loads
+	const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+	const int * __restrict__ bb = batch_base + ((size_t) batch_ptr[t] * (COOB_THREADS / WAVE) + wave) * K;
+	constexpr int BSTRIDE = (COOB_THREADS / WAVE) * K;      // ints of base columns per batch
+	const size_t e0 = (size_t) batch_ptr[t] * BATCH + (size_t) tid;
+	__syncthreads();
+	if (nb > 0)
 	{
-		coob_load<T, UNIT>(q0, ent, val, at(b0) + tid);
-		coob_load<T, UNIT>(q1, ent, val, at(b0 + 1) + tid);
+		// nb is a multiple of 3 (the builder appends all-padding batches), and two more batches of entries / base columns lie behind
+		// every workgroup's last (the next workgroup's, or slack at the very end): no index below is clamped and no step is conditional
+		CoobBatch<T, UNIT, K> q0, q1, q2;
+		T xa[K], xb[K], xc[K];
+		coob_load<T, UNIT, K>(q0, ent, val, e0);
+		coob_load<T, UNIT, K>(q1, ent, val, e0 + BATCH);
+		coob_gather<T, UNIT, K>(xa, q0, x, bb);
+		// one step = one batch: entry loads of the batch after the next, gathers of the NEXT batch, then this batch's adds into LDS.
+		// Vector memory operations complete in issue order, so the order of issue decides what a wait drains: the next step's
+		// gathers need the entries loaded here, and with those loads issued BEFORE this step's gathers that wait leaves the
+		// gathers in flight (the other order drained the queue at every step). The barrier keeps the 16 waves on one stretch of x.
+		#define COOB_STEP(QA, QB, QC, XA, XB, s, k3)                                                                \
+		{                                                                                                         \
+			coob_load<T, UNIT, K>(QC, ent, val, e0 + (size_t) ((s) + 2) * BATCH);                              \
+			__builtin_amdgcn_sched_barrier(0);   /* entry loads BEFORE the gathers: see below */               \
+			coob_gather<T, UNIT, K>(XB, QB, x, bb + (size_t) ((s) + 1) * BSTRIDE);                             \
+			__builtin_amdgcn_sched_barrier(0);   /* nothing that consumes XA may move above the gathers */     \
+			coob_add<T, UNIT, K>(XA, QA, ys, unit);                                                            \
+			if (sync_mask & (1 << (k3)))                                                                       \
+				__syncthreads();                                                                           \
+		}
+		for (int s = 0; s < nb; s += 3)
+		{
+			COOB_STEP(q0, q1, q2, xa, xb, s, 0)
+			COOB_STEP(q1, q2, q0, xb, xc, s + 1, 1)
+			COOB_STEP(q2, q0, q1, xc, xa, s + 2, 2)
+		}
+		#undef COOB_STEP
 	}
 	__syncthreads();
-	int since = 0;
-	// three batches rotate through q0, q1, q2 (compile-time names: registers, not an indexed array)
-	for (int b = b0; b < b1; b += 3)
-	{
-		coob_step<T, UNIT>(q0, q2, ent, val, xblk(b), ys, unit, at(b), at(b + 1), at(b + 2), tid);
-		if (++since == sync_every) { since = 0; __syncthreads(); }    // keep the waves of the workgroup on the same column blocks
-		if (b + 1 < b1)
-		{
-			coob_step<T, UNIT>(q1, q0, ent, val, xblk(b + 1), ys, unit, at(b + 1), at(b + 2), at(b + 3), tid);
-			if (++since == sync_every) { since = 0; __syncthreads(); }
-		}
-		if (b + 2 < b1)
-		{
-			coob_step<T, UNIT>(q2, q1, ent, val, xblk(b + 2), ys, unit, at(b + 2), at(b + 3), at(b + 4), tid);
-			if (++since == sync_every) { since = 0; __syncthreads(); }
-		}
-	}
-	__syncthreads();
-	// local row l = chunk (l / 16) of this workgroup, row l % 16 of the chunk; its chunks are j, j + 32, j + 64, ... of the range
-	const int r0 = range_row[range], r1 = range_row[range + 1];
+	// local row l = row l % 16 of the workgroup's chunk l / 16 (chunk_row: first row of every chunk the deal gave it, in row order)
+	const int r1 = range_row[range + 1];
+	const int * __restrict__ cr = chunk_row + chunk_ptr[t];
 	const int k0 = range_long[range], nlong = range_long[range + 1] - k0;     // split rows of this range: the last `nlong` LDS slots
 	const int nnorm = nloc - nlong;
 	for (int l = tid; l < nnorm; l += COOB_THREADS)
 	{
-		const int row = r0 + ((l / chunk_rows) * COOB_WGS + j) * chunk_rows + l % chunk_rows;
+		const int row = cr[l / chunk_rows] + l % chunk_rows;
 		if (row < r1)
 			y[row] = (T) (beta ? (double) y[row] + ys[l] : ys[l]);
 	}
-	if (tid < nlong)
-		carry[(size_t) (k0 + tid) * COOB_WGS + j] = (T) ys[nnorm + tid];
+	for (int l = tid; l < nlong; l += COOB_THREADS)
+		carry[(size_t) (k0 + l) * COOB_WGS + j] = (T) ys[nnorm + l];
 }
 
 // adds the 32 partial sums of every split row to y, in workgroup order (deterministic given the partial sums)
@@ -366,28 +357,31 @@ coo_blocked_fixup_kernel(const int * __restrict__ long_row, const T * __restrict
 int coo_blocked_wgs_per_range() { return COOB_WGS; }
 int coo_blocked_chunk_rows() { return COOB_CHUNK; }
 int coo_blocked_max_long_rows() { return 64; }     // split rows per range (LDS slots set aside in every workgroup)
-int coo_blocked_batch_entries() { return COOB_U * COOB_THREADS; }         // entries one workgroup takes per batch
-int coo_blocked_entry_slack() { return COOB_U * COOB_THREADS + 64; }      // spare entries behind the entry arrays (branch-free loads)
+int coo_blocked_spare_slots() { return COOB_SPARE; }
+int coo_blocked_slot_bits() { return COOB_SLOT_BITS; }
+// entries per lane and batch: with a value stream three batches of (entry, value) per lane are live, 4 keep that in registers
+int coo_blocked_batch_entries(bool unit) { return (unit ? 8 : 4) * COOB_THREADS; }
 
 int
 coo_blocked_rows_cap(bool f32)
 {
-	// rows of y one workgroup keeps in LDS: the CU's 160 KiB less a little for the runtime, at most what 16 bits index
+	// rows of y one workgroup keeps in LDS: the CU's 160 KiB less a little for the runtime, at most what the slot bits index
 	(void) f32;                                                    // the LDS copy of y is fp64 for both precisions
 	const int bytes = 160 * 1024 - 512;
 	int rows = bytes / 8 / COOB_CHUNK * COOB_CHUNK;
 	if (const char * e = getenv("SPMV_MI355X_COOB_ROWS"))          // tests: a small cap makes small matrices take several passes
 		if (atoi(e) >= COOB_CHUNK && atoi(e) <= rows)
-			rows = atoi(e) / COOB_CHUNK * COOB_CHUNK + coo_blocked_max_long_rows();
-	return std::min(rows, 65536 / COOB_CHUNK * COOB_CHUNK - COOB_CHUNK) - coo_blocked_max_long_rows();
+			rows = atoi(e) / COOB_CHUNK * COOB_CHUNK + coo_blocked_max_long_rows() + COOB_SPARE;
+	return std::min(rows, (1 << COOB_SLOT_BITS) / COOB_CHUNK * COOB_CHUNK - COOB_CHUNK) - coo_blocked_max_long_rows() - COOB_SPARE;
 }
 
-template <typename T>
+template <typename T, bool UNIT>
 static int
-coo_blocked_launch(const int * wg_rows, const int * range_row, const int * seg_blk, const int * range_blk, const int * range_long,
+coo_blocked_launch(const int * wg_rows, const int * range_row, const int * chunk_ptr, const int * chunk_row, const int * batch_ptr, const int * batch_base, const int * range_long,
 		const int * long_row, int num_long, const unsigned * ent, const void * val, const void * x, void * y, void * carry, int num_ranges,
-		int num_blocks, int block_cols, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+		int chunk_rows, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
+	constexpr int K = UNIT ? 8 : 4;
 	// The layout assumes ONE workgroup per CU (32 per XCD, in step): with less than half of the CU's 160 KiB each, two could share
 	// a CU and leave another idle — ask for more than half.
 	lds_bytes = std::max(lds_bytes, 84 * 1024);
@@ -397,8 +391,7 @@ coo_blocked_launch(const int * wg_rows, const int * range_row, const int * seg_b
 	HIP_TRY(hipGetDevice(&dev));
 	if (dev >= 0 && dev < 64 && lds_bytes > granted[dev])
 	{
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&coo_blocked_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&coo_blocked_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&coo_blocked_kernel<T, UNIT, K>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 		granted[dev] = lds_bytes;
 	}
 	const unsigned grid = (unsigned) num_ranges * COOB_WGS;
@@ -407,14 +400,10 @@ coo_blocked_launch(const int * wg_rows, const int * range_row, const int * seg_b
 	if (grid == 0)
 		return 0;
 	const int per_xcd = num_ranges / NUM_XCD;
-	// column blocks between workgroup barriers (measured on the soc-LiveJournal1 twin: 1, 2 and 4 within 2 %, never: +5 %)
-	static const int sync_every = [] { const char * e = getenv("SPMV_MI355X_COOB_SYNC"); return e ? atoi(e) : 1; }();
-	if (cfg.unit)
-		hipLaunchKernelGGL((coo_blocked_kernel<T, true>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, wg_rows, range_row, seg_blk, range_blk,
-				range_long, ent, (const T *) nullptr, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, block_cols, sync_every, (T) cfg.unit_value, cfg.beta);
-	else
-		hipLaunchKernelGGL((coo_blocked_kernel<T, false>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, wg_rows, range_row, seg_blk, range_blk,
-				range_long, ent, (const T *) val, (const T *) x, (T *) y, (T *) carry, per_xcd, num_blocks, block_cols, sync_every, (T) 0, cfg.beta);
+	// steps of the period-3 loop that end with a workgroup barrier (bit k = step k): 7 = every batch
+	static const int sync_mask = [] { const char * e = getenv("SPMV_MI355X_COOB_SYNC"); return e ? atoi(e) & 7 : 7; }();
+	hipLaunchKernelGGL((coo_blocked_kernel<T, UNIT, K>), dim3(grid), dim3(COOB_THREADS), lds_bytes, stream, wg_rows, range_row, chunk_ptr, chunk_row, batch_ptr, batch_base,
+			range_long, ent, (const T *) val, (const T *) x, (T *) y, (T *) carry, per_xcd, chunk_rows, sync_mask, (T) (UNIT ? cfg.unit_value : 0), cfg.beta);
 	HIP_TRY(hipGetLastError());
 	if (num_long > 0)
 	{
@@ -426,14 +415,15 @@ coo_blocked_launch(const int * wg_rows, const int * range_row, const int * seg_b
 }
 
 int
-launch_coo_blocked(bool f32, const int * wg_rows, const int * range_row, const int * seg_blk, const int * range_blk, const int * range_long,
+launch_coo_blocked(bool f32, const int * wg_rows, const int * range_row, const int * chunk_ptr, const int * chunk_row, const int * batch_ptr, const int * batch_base, const int * range_long,
 		const int * long_row, int num_long, const unsigned * ent, const void * val, const void * x, void * y, void * carry, int num_ranges,
-		int num_blocks, int block_cols, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+		int chunk_rows, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
 {
-	return f32 ? coo_blocked_launch<float>(wg_rows, range_row, seg_blk, range_blk, range_long, long_row, num_long, ent, val, x, y, carry, num_ranges,
-	                                       num_blocks, block_cols, lds_bytes, cfg, stream, grid_out)
-	           : coo_blocked_launch<double>(wg_rows, range_row, seg_blk, range_blk, range_long, long_row, num_long, ent, val, x, y, carry, num_ranges,
-	                                        num_blocks, block_cols, lds_bytes, cfg, stream, grid_out);
+	#define COOB_ARGS wg_rows, range_row, chunk_ptr, chunk_row, batch_ptr, batch_base, range_long, long_row, num_long, ent, val, x, y, carry, num_ranges, chunk_rows, lds_bytes, cfg, stream, grid_out
+	if (cfg.unit)
+		return f32 ? coo_blocked_launch<float, true>(COOB_ARGS) : coo_blocked_launch<double, true>(COOB_ARGS);
+	return f32 ? coo_blocked_launch<float, false>(COOB_ARGS) : coo_blocked_launch<double, false>(COOB_ARGS);
+	#undef COOB_ARGS
 }
 
 }  // namespace spmv

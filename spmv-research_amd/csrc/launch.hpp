@@ -102,12 +102,14 @@ int launch_coo(bool f32, int items_per_lane, const int * rowind, const int * col
 int coo_blocked_rows_cap(bool f32);                                    // rows of y one workgroup can keep in LDS
 int coo_blocked_wgs_per_range();                                       // workgroups a row range is dealt to (32 = CUs per XCD)
 int coo_blocked_chunk_rows();                                          // rows per chunk of that round-robin deal (16)
-int coo_blocked_batch_entries();                                       // entries a workgroup consumes per batch (8 per lane)
-int coo_blocked_entry_slack();                                         // spare entries the entry / value arrays need behind their end
+int coo_blocked_batch_entries(bool unit);                              // entries of one batch of a workgroup (8 or 4 per lane)
+int coo_blocked_spare_slots();                                         // LDS slots behind a workgroup's rows that padding entries add into
+int coo_blocked_slot_bits();                                           // low bits of an entry that hold the LDS slot (the rest: column - base)
 int coo_blocked_max_long_rows();                                       // rows per range that may be split over its workgroups
-int launch_coo_blocked(bool f32, const int * wg_rows, const int * range_row, const int * seg_blk, const int * range_blk, const int * range_long,
+int launch_coo_blocked(bool f32, const int * wg_rows, const int * range_row, const int * chunk_ptr, const int * chunk_row, const int * batch_ptr, const int * batch_base,
+		const int * range_long,
 		const int * long_row, int num_long, const unsigned * ent, const void * val, const void * x, void * y, void * carry, int num_ranges,
-		int num_blocks, int block_cols, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
+		int chunk_rows, int lds_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out);
 
 // ---- small utility kernels (kernels_csr.hip)
 int launch_expand_rows(const int * row_ptr, int m, int * rowind, hipStream_t stream);   // CSR -> COO row indices (mkl_coo.cpp:79-90)

@@ -235,9 +235,9 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 		case SPMV_MI355X_CSR_MERGE:
 			if (A->coob_ranges > 0)
 			{
-				rc = launch_coo_blocked(A->f32, A->d_coob_wg_rows, A->d_coob_range_row, A->d_coob_seg_blk, A->d_coob_range_blk, A->d_coob_range_long,
-						A->d_coob_long_row, A->coob_num_long, A->d_coob_ent, A->d_val, x, y, A->d_coob_carry, A->coob_ranges, A->coob_blocks,
-						A->coob_block_cols, A->coob_lds, cfg, st, &grid);
+				rc = launch_coo_blocked(A->f32, A->d_coob_wg_rows, A->d_coob_range_row, A->d_coob_chunk_ptr, A->d_coob_chunk_row, A->d_coob_batch_ptr, A->d_coob_batch_base, A->d_coob_range_long,
+						A->d_coob_long_row, A->coob_num_long, A->d_coob_ent, A->d_val, x, y, A->d_coob_carry, A->coob_ranges,
+						A->coob_chunk_rows, A->coob_lds, cfg, st, &grid);
 				break;
 			}
 			rc = launch_merge(A->f32, A->merge_ipt, A->d_row_ptr, A->d_col, A->d_val, x, y, (int) A->m, (int) A->nnz,
@@ -256,9 +256,9 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 		case SPMV_MI355X_COO:
 			if (A->coob_ranges > 0)
 			{
-				rc = launch_coo_blocked(A->f32, A->d_coob_wg_rows, A->d_coob_range_row, A->d_coob_seg_blk, A->d_coob_range_blk, A->d_coob_range_long,
-						A->d_coob_long_row, A->coob_num_long, A->d_coob_ent, A->d_val, x, y, A->d_coob_carry, A->coob_ranges, A->coob_blocks,
-						A->coob_block_cols, A->coob_lds, cfg, st, &grid);
+				rc = launch_coo_blocked(A->f32, A->d_coob_wg_rows, A->d_coob_range_row, A->d_coob_chunk_ptr, A->d_coob_chunk_row, A->d_coob_batch_ptr, A->d_coob_batch_base, A->d_coob_range_long,
+						A->d_coob_long_row, A->coob_num_long, A->d_coob_ent, A->d_val, x, y, A->d_coob_carry, A->coob_ranges,
+						A->coob_chunk_rows, A->coob_lds, cfg, st, &grid);
 				break;
 			}
 			rc = launch_coo(A->f32, A->coo_k, A->d_rowind, A->d_col, A->d_val, x, y, (int) A->m, A->nnz, A->coo_num_waves,

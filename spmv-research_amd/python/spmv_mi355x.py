@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libspmv_mi355x.so")
+LIB_PATH = os.environ.get("SPMV_MI355X_LIB") or os.path.join(PKG_ROOT, "lib", "libspmv_mi355x.so")     # the override is for kernel experiments
 
 CSR_SCALAR, CSR_VECTOR, CSR_MERGE, SELL_C_SIGMA, COO, CSR_STREAM = range(6)
 FORMATS = {"csr_scalar": CSR_SCALAR, "csr_vector": CSR_VECTOR, "csr_merge": CSR_MERGE,
