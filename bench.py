@@ -18,18 +18,21 @@ The matrices are synthetic twins (no SuiteSparse file exists in the reference tr
 file under $SPMV_MTX_DIR/<name>.mtx is loaded through the product's own Matrix-Market reader instead).
 
 metric/value: GFLOP/s = 2*nnz / t (true stored nnz; the reference's printed GFLOPS is ~2x inflated for general
-matrices). roofline.achieved: ALGORITHMIC bytes B_alg = nnz*(sizeof(V)+4) + (m+1)*4 + (n+m)*sizeof(V)
-per launch / mean kernel time from HIP events recorded on the launch stream over the timed region.
-roofline.frac == roofline.frac_algorithmic is that CSR-normalised figure; roofline.frac_hbm_measured is the PMC
-traffic of the same kernel build / time / peak (only when profiles/traffic_*.json holds a record taken with these
-kernel sources and this format).
+matrices). ONE clock for value, hbm_pct_of_peak and every roofline fraction: the wall time per step of the synchronize
+bracket around the K timed launches (ms_per_step); the HIP-event time of the same launches, recorded on the launch stream, is kept
+beside it as roofline.kernel_ms. roofline.achieved: ALGORITHMIC bytes B_alg = nnz*(sizeof(V)+4) + (m+1)*4 + (n+m)*sizeof(V) per
+launch / ms_per_step. roofline.frac == roofline.frac_algorithmic is that CSR-normalised figure (a format that stores fewer bytes
+than CSR scores above what it moves); roofline.frac_hbm_measured is the PMC traffic of the same kernel build / time / peak (only
+when profiles/traffic_*.json holds a record taken with these kernel sources and this format); roofline.frac_floor is the same
+headline with every index-free mode of the format switched off (what a matrix without the twin's translation invariance gets).
 
 Order of events at N = 1 (everything before the timed steps is reported under setup_s, none of it is timed): generate the twin ->
-convert (GPU) -> first use of the handle's own x / y: the engine places the vectors and its arrays in HBM by timing its own
-kernel at candidate sites (csrc/placement.hip; worth up to 13 % on this device, profiles/r02_placement.md) -> 6 s idle while the
-driver clears the memory that search returned -> W warm-up launches -> settle (batches until two agree within 0.5 %, >= 500
-launches; the reference driver warms GPU kernels with 1000 calls) -> EXACTLY K timed launches between HIP events, inside a
-synchronize bracket (K = 1000 by default: 1.3 s of the headline kernel).
+convert (GPU) -> first use of the handle's own x / y: bench.py asks for engine-placed vectors (opts.placement = 1): the first handle
+of the process walks the device's free memory once for two vector pools in blocks of different class, every handle then takes its
+vectors from the pool its kernel runs faster in (csrc/placement.hip; worth up to 13 % on this device, profiles/r02_placement.md)
+-> W warm-up launches -> settle (batches until two agree within 0.5 %, >= 500 launches; the reference driver warms GPU kernels
+with 1000 calls) -> EXACTLY K timed launches between HIP events, inside a synchronize bracket (K = 1000 by default: 1.3 s of the
+headline kernel; with K < 200 five such windows are timed and the median one is reported with the spread).
 """
 import argparse
 import hashlib
@@ -116,9 +119,9 @@ def parse(argv=None):
                          "host copy of the matrix never exceeds a piece; 0 = the whole block at once")
     ap.add_argument("--piece-handles", action="store_true",
                     help="N>1: one handle per piece instead of one handle converted from the pieces in device memory (tests)")
-    ap.add_argument("--idle-after-placement", type=float, default=6.0,
-                    help="seconds without launches after the engine has placed the vectors: the driver clears the ~165 GiB the search "
-                         "returned in the background, which slows launches by up to 5.5 %% until it is done (profiles/r02_placement.md §6)")
+    ap.add_argument("--idle-after-placement", type=float, default=0.0,
+                    help="extra seconds without launches after the engine has placed the vectors (the driver clears the ballast the one "
+                         "walk returned in the background; the settle phase runs through it; profiles/r02_placement.md §6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -282,7 +285,7 @@ def cold_launches(torch, M, xp, yp, sp, count=15, flush_bytes=1 << 30):
     return float(np.median(ts))
 
 
-def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_warm_seconds=0.0, idle_after_placement=6.0, windows=1,
+def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_warm_seconds=0.0, idle_after_placement=0.0, windows=1,
                 cold=False):
     """Build one handle, run warm-up + `windows` x `steps` back-to-back launches, each window timed by HIP events on the launch
     stream inside a synchronize bracket, check sampled rows. Returns a dict with the measured figures (the MEDIAN window's) and leaves
@@ -294,6 +297,8 @@ def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_war
     if x_host is None:
         x_host = np.random.default_rng(14).uniform(-1.0, 1.0, n).astype(np_dtype)
     t0 = time.time()
+    opts = dict(opts)
+    opts.setdefault("placement", 1)          # vectors from the engine's pools (csrc/placement.hip): opt-in, and bench.py opts in
     M = E.Matrix(A["row_ptr"], A["col_idx"], A["values"], m, n, fmt, np_dtype, **opts)
     t_conv = time.time() - t0
     # the handle's own x / y pair: allocated and PLACED by the engine (csrc/placement.hip — where y lives relative to the value
@@ -302,10 +307,10 @@ def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_war
     M.upload_x(x_host)
     t_place = time.time() - t0
     if t_place > 0.15 and idle_after_placement > 0:
-        # the placement pass has just returned ~165 GiB of ballast and unused sites to the driver, which clears freed memory in the
-        # background: launched into that, the kernel alternates between its normal level and one 5.5 % slower for 4-5 s; after
-        # 5.5 idle seconds it is stable from the first batch on (time series in profiles/r02_placement.md §6). Not part of any timed
-        # region; reported in setup_s.
+        # the first handle of the process has just walked the device's free memory for the vector pools and returned the ballast; the
+        # driver clears freed memory in the background, and kernels launched into that alternate between their normal level and one
+        # ~5 % slower (time series in profiles/r02_placement.md §6). The settle phase below runs through it; --idle-after-placement
+        # adds an idle wait on top (default 0). Not part of any timed region; reported in setup_s.
         time.sleep(idle_after_placement)
         t_place += idle_after_placement
     xp, yp = M.x_device(), M.y_device()

@@ -93,13 +93,18 @@ typedef struct {
 	                           with merge-path-balanced row ranges — never chosen unless asked for                                  */
 	int  sell_window;       /* SELL, 64-row slices: a workgroup owns a group of consecutive slices, copies the group's column window of
 	                           x into LDS and gathers from there; column indices are 16-bit offsets into the window (for banded /
-	                           FEM matrices; csrc/kernels_sell_window.hip). 0 = auto (when every group's window fits), 1 = on, 2 = off */
+	                           FEM matrices; csrc/kernels_sell_window.hip). 0 = auto (when sell_sigma, sell_delta and convert_on are at their defaults
+	                           and every group's window fits; rows are then sorted inside a slice group: sigma = 64 * sell_group), 1 = on, 2 = off.
+	                           spmv_mi355x_sell_layout() does not decode this layout: name a sell_sigma (or sell_window = 2) for layout parity */
 	int  kahan;             /* CSR_SCALAR: 1 = Kahan-compensated row sums, the reference's CUSTOM_KAHAN build (csr.cpp:353-373); same
 	                           operations in the same order -> bit-identical to it                                             */
 	int  sell_group;        /* sell_window: slices per workgroup (1, 2, 4, 8 or 16; times sell_split at most 16 wavefronts); 0 = auto */
-	int  placement;         /* where y, x and the index arrays live relative to the value array ("output vectors placed by the
-	                           engine" below): 0 = auto (a tuning pass of ~250 launches at the first use of the handle's own
-	                           vectors when y is 8 MiB or more), 2 = off                                                         */
+	int  placement;         /* where the handle's vectors live relative to its value array ("vectors placed by the engine" below):
+	                           0 = off (default: plain allocations), 1 = on (slices of the device's two vector pools; the first handle
+	                           of a process that asks makes ONE walk through the device's free memory to find them), 2 = off,
+	                           3 = 1 + a search over the handle's matrix arrays (worth 1-2 %, ~500 launches).
+	                           SPMV_MI355X_PLACEMENT in the environment overrides: 0 off, 1 on, 2 on + log on stderr, 3, 4 (diagnostic) */
+	int  placement_budget_gib;  /* transient memory the walk may hold, GiB (0 = 96; it never takes the device's last 8 GiB)              */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */
@@ -165,27 +170,30 @@ int  spmv_mi355x_kernel_info(const spmv_mi355x_matrix * A, char * name_out, long
 int  spmv_mi355x_copy_device_async(void * dst_dev, const void * src_dev, long bytes, void * hip_stream);
 
 /* Device buffers owned by the handle (allocated lazily by the host-buffer entry points): x has n values, y has rows + 64
- * (the reference driver's slack, bench_spmv.cpp:606-609). y is placed as an OUTPUT vector (below). */
+ * (the reference driver's slack, bench_spmv.cpp:606-609). With opts.placement = 1 both are placed by the engine (below). */
 void * spmv_mi355x_x_device(spmv_mi355x_matrix * A);
 void * spmv_mi355x_y_device(spmv_mi355x_matrix * A);
 int  spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host);      /* rows values into the handle's y (for y += A x) */
 
-/* ---- output vectors placed by the engine -------------------------------------------------------------------------- */
-/* The 288 GiB of an MI355X behave as 32 GiB regions, and the same kernel on the same matrix and x takes 1.28, 1.30 or 1.42 ms
- * (nlpkkt240 twin) depending only on which region y lives in; which memory an allocation gets is the driver's choice
- * (profiles/r02_placement.md). A vector the handle's SpMV writes is therefore placed by timing the handle's own
- * kernel on it: when a candidate from deeper in the pool is clearly faster, it replaces the first one. (The handle's own pass also
- * moves its arrays of up to 8 GiB — value array, index arrays, x — the same way.) The handle's own y
- * (spmv_mi355x_y_device, used by spmv_mi355x_spmv) is placed this way; output_alloc gives callers of the device-pointer entry
- * points the same for their vectors (bytes >= (rows + 64) values; smaller or < 8 MiB: a plain allocation). Zero-filled.
- * The search holds up to ~165 GiB of the device's free memory for its duration (ballast between the candidate sites; it never
- * takes the last 8 GiB and stops early when less is free) and returns everything but the chosen sites; the driver clears returned
- * memory in the background: kernels launched into that alternate between their normal time and one 5.5 % longer for 4-5 s; after
- * 5.5 s without launches the device is done (bench.py idles through it; profiles/r02_placement.md §6).
- * SPMV_MI355X_PLACEMENT=0 turns the search off, =2 reports it on stderr. No reference counterpart (the reference's GPU
- * backends hipMalloc their vectors in the constructor, GPU_clean/csr_rocm_vector.cpp:77-86). */
+/* ---- vectors placed by the engine --------------------------------------------------------------------------------- */
+/* The 288 GiB of an MI355X behave as 32 GiB blocks that fall into classes, and the same kernel on the same matrix and x takes 1.28 or
+ * 1.46 ms (nlpkkt240 twin) depending only on whether y lives in a block of the same class as the value array; which memory an
+ * allocation gets is the driver's choice (profiles/r02_placement.md). With opts.placement = 1 (or SPMV_MI355X_PLACEMENT
+ * >= 1) the engine keeps, per process and device, two VECTOR POOLS (1-4 GiB each) in blocks of different class: the first handle that
+ * needs a vector of 8 MiB or more walks the device's free memory once — candidates 16 GiB of ballast apart, timed with the handle's
+ * own kernel, until one differs from the first by 4 %; at most opts.placement_budget_gib (96) of ballast, returned when the walk
+ * ends — and every later vector of any handle is a slice of the pool in which that handle's kernel runs faster (two trials of six
+ * launches). The handle's own pair (spmv_mi355x_x_device / y_device, used by spmv_mi355x_spmv) is placed this way; output_alloc /
+ * input_alloc give callers of the device-pointer entry points the same for vectors the handle's SpMV writes / reads (bytes >= (rows +
+ * 64) resp. cols values; smaller, under 8 MiB or with placement off: a plain allocation). Zero-filled. Free with output_free.
+ * OFF by default: the walk holds tens of GiB for a fraction of a second, its free-memory check is racy against other processes on the
+ * same GPU, and the driver clears the returned ballast in the background for a few seconds, during which any process's kernels on that
+ * GPU run up to 5 % slower (profiles/r02_placement.md §6). placement_release frees a device's pools (no vector of them may be live).
+ * No reference counterpart (the reference's GPU backends hipMalloc their vectors in the constructor, GPU_clean/csr_rocm_vector.cpp:77-86). */
 int  spmv_mi355x_output_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out);
+int  spmv_mi355x_input_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out);
 int  spmv_mi355x_output_free(void * p);
+int  spmv_mi355x_placement_release(int device /* -1: every device */);
 
 /* ---- solver callers of spmv() ---------------------------------------------------------------- */
 /* Device-resident replacements for the reference's two Krylov drivers, which call MF->spmv() with a vector that changes

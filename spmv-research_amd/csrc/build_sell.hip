@@ -343,7 +343,7 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 		if (hi < 0)
 			lo = 0;
 		const long w = hi < 0 ? 1 : (long) hi - lo + 1;
-		if (w > 65536 || w * (long) A->vbytes > lds_budget_bytes)
+		if (w > 65535 || (w + 1) * (long) A->vbytes > lds_budget_bytes)          // one more LDS slot behind the window holds a zero
 			too_wide++;
 		grp[(size_t) 4 * g] = lo;
 		grp[(size_t) 4 * g + 1] = (int) std::min<long>(w, 0x7fffffffL);
@@ -384,7 +384,7 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 64)
 	for (long sl = 0; sl < num_slices; sl++)
 	{
-		const int lo = grp[(size_t) 4 * (sl / NS)];
+		const int lo = grp[(size_t) 4 * (sl / NS)], gw = grp[(size_t) 4 * (sl / NS) + 1];
 		const int64_t vb = sdesc[2 * sl], ib = sdesc[2 * sl + 1];
 		const long width = (sdesc[2 * sl + 2] - vb) / C;              // a multiple of 4
 		for (int r = 0; r < C; r++)
@@ -397,8 +397,9 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 				js = rp[o];
 				len = rp[o + 1] - rp[o];
 			}
-			// padding: value 0 times a window entry the row already reads (its last column), or the window's first
-			const unsigned short pad = len > 0 ? (unsigned short) (ci[js + len - 1] - lo) : (unsigned short) 0;
+			// padding: value 0 times a window entry the row already reads (its last column); an EMPTY row reads the zero the kernel
+			// keeps behind the window (its y must be 0 whatever x holds: 0 * Inf from a neighbour's column would make it NaN)
+			const unsigned short pad = len > 0 ? (unsigned short) (ci[js + len - 1] - lo) : (unsigned short) gw;
 			for (long k = 0; k < width; k++)
 			{
 				val[(size_t) (vb + k * C + r)] = k < len ? va[js + k] : 0.0;
@@ -412,7 +413,7 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 	A->sellw_groups = (int) num_groups;
 	A->sellw_ns = NS;
 	A->sell_split = S;
-	A->sellw_lds = (int) (((long) max_w * A->vbytes + 15) / 16 * 16);
+	A->sellw_lds = (int) (((long) (max_w + 1) * A->vbytes + 15) / 16 * 16);
 	{
 		// XCD map over the groups, balanced by their stored entries
 		std::vector<int64_t> gp((size_t) num_groups + 1, 0);
@@ -471,7 +472,9 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 		return 1;
 	}
 	// ---- x window in LDS + 16-bit indices (banded / FEM matrices): sell_window 0 = auto, 1 = on (error when not applicable), 2 = off
-	if (C == 64 && o.sell_window != 2 && (o.sell_window == 1 || (o.sell_delta == 0 && o.convert_on == 0)))
+	// (auto only when sell_sigma, sell_delta and convert_on are all at their defaults: the window layout sorts inside a slice group, i.e. with
+	// its own sigma = 64 * slices per group — a caller who names a sigma, e.g. for the a6'/a7 layout parity entry point, gets that sigma)
+	if (C == 64 && o.sell_window != 2 && (o.sell_window == 1 || (o.sell_delta == 0 && o.convert_on == 0 && o.sell_sigma == 0)))
 	{
 		const long slices = (lm + 63) / 64;
 		const double mean = lm > 0 ? (double) A->nnz / lm : 0;

@@ -16,8 +16,10 @@ dev_alloc_bytes(void ** p, size_t bytes)
 void
 free_all(spmv_mi355x_matrix * A)
 {
+	(void) vector_free(A->d_x);            // the handle's vectors may be slices of the device's vector pools (placement.hip)
+	(void) vector_free(A->d_y);
 	void * ptrs[] = {A->d_row_ptr, A->d_col, A->d_val, A->d_coords, A->d_carry_row, A->d_carry_val, A->d_slice_ptr,
-	                 A->d_row_of_sorted, A->d_rowind, A->d_x, A->d_y, A->d_sell_desc, A->d_sell_idx, A->d_win_row, A->d_win_lo,
+	                 A->d_row_of_sorted, A->d_rowind, A->d_sell_desc, A->d_sell_idx, A->d_win_row, A->d_win_lo,
 	                 A->d_win_w, A->d_col16, A->d_coob_wg_rows, A->d_coob_range_row, A->d_coob_chunk_ptr, A->d_coob_chunk_row, A->d_coob_batch_ptr, A->d_coob_batch_base, A->d_coob_ent, A->d_coob_range_long, A->d_coob_long_row, A->d_coob_carry, A->d_sellw_grp};
 	for (void * p : ptrs)
 		if (p)

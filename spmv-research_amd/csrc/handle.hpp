@@ -75,11 +75,10 @@ struct spmv_mi355x_matrix {
 	// host-buffer path
 	void * d_x = nullptr;
 	void * d_y = nullptr;
-	bool placement_off = false;            // opts.placement == 2
+	int placement_level = 0;               // opts.placement: 0 / 2 = off, 1 = the device's vector pools, 3 = + search over the matrix arrays
+	long placement_budget_gib = 0;         // transient ballast the one walk of a device may hold (0 = 96)
 	const void * cached_x_host = nullptr;
 	bool y_downloaded = false;
-	double place_fast_us = 0;         // placement.hip: kernel time on an output vector known to sit in a fast region
-	double place_only_us = 0;         //                the one time a complete walk saw
 	bool always_copy = false;
 	hipStream_t stream = nullptr;
 
@@ -97,8 +96,9 @@ int dev_alloc_bytes(void ** p, size_t bytes);
 int build_sell_delta_resident(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * d_rp, const int * d_ci, const double * d_va);   // build_sell.hip
 void init_handle(spmv_mi355x_matrix * A, int format, int precision, int device, const spmv_mi355x_opts & o, long m, long n, long nnz);   // spmv_mi355x.hip
 int ensure_x(spmv_mi355x_matrix * A);                                    // spmv_mi355x.hip: stream + the handle's own (zeroed) x
-int tune_placement(spmv_mi355x_matrix * A);                              // placement.hip: move y, x and the side arrays to better blocks of HBM
-int dev_alloc_output(spmv_mi355x_matrix * A, void ** p, size_t bytes);   // placement.hip: a vector A's SpMV writes (placed by timing, zero-filled)
+int tune_placement(spmv_mi355x_matrix * A);                              // placement.hip: allocates the handle's y (and re-homes its x) in the device's vector pools
+int place_vector(spmv_mi355x_matrix * A, void ** out, size_t bytes, bool is_output);   // placement.hip: a zero-filled vector A's SpMV writes / reads
+int vector_free(void * p);                                               // placement.hip: what place_vector returned (pool slice or plain allocation)
 template <typename T>
 inline int
 dev_alloc(T ** p, size_t count)

@@ -108,6 +108,8 @@ sell_window_kernel(const int * __restrict__ grp, const int64_t * __restrict__ sd
 		sellw_load2<T, NT>(p, ip + (size_t) g * WAVE, vp + (size_t) g * 4 * WAVE, ip + (size_t) (g + S) * WAVE, vp + (size_t) (g + S) * 4 * WAVE);
 	for (int i = threadIdx.x; i < w; i += blockDim.x)
 		xs[i] = x[lo + i];
+	if (threadIdx.x == 0)
+		xs[w] = 0;                          // what the padding of EMPTY rows points at: 0 * 0, never 0 * Inf from some other row's column
 	__syncthreads();
 	T s = 0;
 	if (active)

@@ -100,6 +100,13 @@ closest(const int32_t * A, long lo, long hi, long target)
 	return (labs(target - (long) A[s]) < labs(target - (long) A[e])) ? s : e;
 }
 
+// every partitioned entry point walks the devices with hipSetDevice: the caller's current device is put back on every way out
+struct DeviceRestore {
+	int saved = -1;
+	DeviceRestore() { if (hipGetDevice(&saved) != hipSuccess) { (void) hipGetLastError(); saved = -1; } }
+	~DeviceRestore() { if (saved >= 0) (void) hipSetDevice(saved); }
+};
+
 }  // namespace
 
 struct spmv_mi355x_partitioned {
@@ -233,6 +240,7 @@ int
 spmv_mi355x_create_partitioned(spmv_mi355x_partitioned ** out, int nparts, const int * devices, int exchange, int format, int precision,
 		long m, long n, long nnz, const int32_t * row_ptr, const int32_t * col_idx, const double * values, const spmv_mi355x_opts * opts_in)
 {
+	DeviceRestore restore;
 	*out = nullptr;
 	if (nparts < 1 || nparts > 64)
 	{
@@ -441,6 +449,7 @@ spmv_mi355x_destroy_partitioned(spmv_mi355x_partitioned * P)
 {
 	if (!P)
 		return 0;
+	DeviceRestore restore;
 	(void) sync_all(P);
 	destroy_parts(P);
 	delete P;
@@ -471,6 +480,7 @@ spmv_mi355x_partitioned_set_always_copy(spmv_mi355x_partitioned * P, int on)
 int
 spmv_mi355x_spmv_partitioned(spmv_mi355x_partitioned * P, const void * x_host, void * y_host)
 {
+	DeviceRestore restore;
 	const size_t slice_bytes = (size_t) P->padded * P->vbytes;
 	if (P->always_copy || P->cached_x_host != x_host)
 	{
@@ -508,6 +518,7 @@ spmv_mi355x_spmv_partitioned(spmv_mi355x_partitioned * P, const void * x_host, v
 int
 spmv_mi355x_time_partitioned(spmv_mi355x_partitioned * P, int iters, double * ms_per_iter_out)
 {
+	DeviceRestore restore;
 	if (sync_all(P))
 		return 1;
 	const auto t0 = std::chrono::steady_clock::now();

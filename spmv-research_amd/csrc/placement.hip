@@ -1,17 +1,27 @@
-// Placement of the vectors beside the matrix in HBM.
+// Placement of the vectors beside the matrix in HBM: two process-wide VECTOR POOLS per device, in blocks of different class.
 //
 // Measured on MI355X (profiles/r02_placement.md): the 288 GiB of a device behave as 32 GiB blocks that fall into classes, and the
 // SAME SpMV kernel on the SAME matrix and x takes 1.25-1.29 ms or 1.46 ms (nlpkkt240 twin) depending only on whether y sits in
 // a block of the same class as the value array (y is 2.6 % of the traffic: ~100 ns per written line, a DRAM row conflict per
-// write-back); x and the index arrays move the time by 1-5 % the same way. Offsets inside a block do not matter. Which physical
-// memory an allocation gets is the driver's choice and differs from process to process; a process that allocates its handle and
-// then its vectors gets them side by side, usually in one block — the "slow timing state" round 1 could not explain.
-// Synthetic write probes rank the blocks differently from the SpMV kernel, so vectors are placed by timing the handle's OWN
-// kernel on candidates taken from deeper and deeper in the pool: earlier candidates and 16 GiB of ballast per step stay allocated
-// during the walk so that the driver has to move on, and everything but the winner is returned at the end.
+// write-back); x moves the time by 1-5 % the same way. Offsets inside a block do not matter. Which physical memory an allocation
+// gets is the driver's choice; a process that allocates its handle and then its vectors gets them side by side, usually in one
+// block — the "slow timing state" round 1 could not explain. Synthetic write probes rank the blocks differently from the SpMV
+// kernel, so classes are told apart by timing a handle's OWN kernel.
+//
+// Round 2 searched per handle (ten sites, ~165 GiB of ballast, ~600 launches, every handle again). Round 3: ONE walk per process and
+// device, made by the first handle that asks (opts.placement = 1 or SPMV_MI355X_PLACEMENT >= 1; OFF by default): candidates for y
+// are taken from deeper and deeper in the driver's pool, 16 GiB of ballast apart, until one runs the handle's kernel 4 % faster or
+// slower than the first — those two candidates are in blocks of different class and are KEPT as the device's two vector pools
+// (1-4 GiB each), the ballast (at most opts.placement_budget_gib, default 96, never the last 8 GiB of the device) goes back. From
+// then on a vector of any handle of the process is a slice of one of the pools: two trials (6 launches each) decide which. A
+// scope guard returns ballast and rejected candidates on every way out. Other processes on the same GPU: the walk's free-memory
+// check (hipMemGetInfo, then hipMalloc) is racy between processes, and a neighbour's kernels run a few % slower for the seconds
+// the driver takes to clear the returned ballast — one more reason why this is opt-in.
+// Level 3 (SPMV_MI355X_PLACEMENT=3 / opts.placement = 3) adds round 2's search over the handle's matrix arrays (worth 1-2 %).
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "handle.hpp"
@@ -21,16 +31,106 @@ namespace spmv {
 namespace {
 
 constexpr size_t PLACE_MIN_BYTES = (size_t) 8 << 20;       // smaller problems run out of the caches
-constexpr size_t BALLAST_STEP = (size_t) 16 << 30;         // blocks are 32 GiB: two candidates per block
-constexpr size_t WALK_LIMIT = (size_t) 160 << 30;
-constexpr size_t KEEP_FREE = (size_t) 8 << 30;             // never take the last of the pool for ballast
+constexpr size_t WALK_STEP = (size_t) 16 << 30;            // blocks are 32 GiB: two candidates per block
+constexpr size_t KEEP_FREE = (size_t) 8 << 30;             // never take the last of the device for ballast
+constexpr size_t POOL_ALIGN = (size_t) 2 << 20;
 constexpr double CONTRAST = 1.04;                          // classes differ by 12-15 % (the two fast ones by 3 %), repeats by < 0.3 %
+constexpr int MAX_DEV = 64;
+
+// SPMV_MI355X_PLACEMENT: unset = what the handle's opts say; 0 = off; 1 = pools; 2 = pools + log; 3 = + search over the matrix arrays;
+// 4 = 3 + the (value array block) x (y block) table of profiles/r02_placement.md §4
+int
+env_level()
+{
+	static const int s = getenv("SPMV_MI355X_PLACEMENT") ? atoi(getenv("SPMV_MI355X_PLACEMENT")) : -1;
+	return s;
+}
 
 int
-setting()
+level_of(const spmv_mi355x_matrix * A)
 {
-	static const int s = getenv("SPMV_MI355X_PLACEMENT") ? atoi(getenv("SPMV_MI355X_PLACEMENT")) : 1;
-	return s;
+	const int e = env_level();
+	return e >= 0 ? e : A->placement_level;
+}
+
+bool
+verbose()
+{
+	return env_level() >= 2;
+}
+
+// returns everything it still holds when it goes out of scope
+struct Held {
+	std::vector<void *> v;
+	~Held() { release(); }
+	void release()
+	{
+		for (void * p : v)
+			if (p)
+				(void) hipFree(p);
+		v.clear();
+	}
+};
+
+struct Pool {
+	char * base = nullptr;
+	size_t size = 0;
+	std::vector<std::pair<size_t, size_t>> free_list;      // (offset, bytes), sorted by offset, coalesced
+	std::vector<std::pair<size_t, size_t>> live;           // (offset, bytes) handed out
+};
+
+struct DevPools {
+	int state = 0;                 // 0 = no walk yet, 1 = two pools of different class, 2 = walked: no contrast seen (plain allocations)
+	Pool pool[2];
+};
+
+DevPools g_dev[MAX_DEV];
+std::mutex g_mu;
+
+void *
+pool_alloc(Pool & p, size_t bytes)
+{
+	bytes = (bytes + POOL_ALIGN - 1) / POOL_ALIGN * POOL_ALIGN;
+	for (size_t i = 0; i < p.free_list.size(); i++)
+		if (p.free_list[i].second >= bytes)
+		{
+			const size_t off = p.free_list[i].first;
+			p.free_list[i].first += bytes;
+			p.free_list[i].second -= bytes;
+			if (p.free_list[i].second == 0)
+				p.free_list.erase(p.free_list.begin() + (long) i);
+			p.live.emplace_back(off, bytes);
+			return p.base + off;
+		}
+	return nullptr;
+}
+
+bool
+pool_free(Pool & p, void * ptr)
+{
+	if (!p.base || (char *) ptr < p.base || (char *) ptr >= p.base + p.size)
+		return false;
+	const size_t off = (size_t) ((char *) ptr - p.base);
+	for (size_t i = 0; i < p.live.size(); i++)
+		if (p.live[i].first == off)
+		{
+			const std::pair<size_t, size_t> blk = p.live[i];
+			p.live.erase(p.live.begin() + (long) i);
+			auto it = std::lower_bound(p.free_list.begin(), p.free_list.end(), blk);
+			it = p.free_list.insert(it, blk);
+			if (it + 1 != p.free_list.end() && it->first + it->second == (it + 1)->first)
+			{
+				it->second += (it + 1)->second;
+				p.free_list.erase(it + 1);
+			}
+			if (it != p.free_list.begin() && (it - 1)->first + (it - 1)->second == it->first)
+			{
+				(it - 1)->second += it->second;
+				p.free_list.erase(it);
+			}
+			return true;
+		}
+	return true;       // inside the pool but not a live block: nothing to do (a double free)
 }
 
 // average microseconds of the handle's kernel reading x and writing y
@@ -45,101 +145,113 @@ kernel_us(spmv_mi355x_matrix * A, const void * x, void * y)
 	return ms * 1e3;
 }
 
-struct Walk {
-	double t_first = 0, t_chosen = 0, seconds = 0;
-	int tries = 1;
-	bool known = false;
-};
+size_t
+budget_bytes(const spmv_mi355x_matrix * A)
+{
+	long gib = A->placement_budget_gib > 0 ? A->placement_budget_gib : 96;
+	if (const char * e = getenv("SPMV_MI355X_PLACEMENT_BUDGET_GIB"))
+		if (atol(e) > 0)
+			gib = atol(e);
+	return (size_t) gib << 30;
+}
 
-// `first` (already allocated, `bytes` long) or a better-placed replacement of it in *chosen; measure(candidate) = kernel
-// microseconds with the candidate in use. The caller moves contents and frees `first` when it lost.
-template <typename Measure>
+// The one walk of a device: find two candidates of different block class under A's kernel (y = candidate), keep them as the pools.
 int
-walk(spmv_mi355x_matrix * A, void * first, size_t bytes, Measure measure, void ** chosen, Walk & w)
+build_pools(spmv_mi355x_matrix * A, DevPools & dp)
 {
 	const auto c0 = std::chrono::steady_clock::now();
-	*chosen = first;
-	w.t_first = w.t_chosen = measure(first);
-	if (w.t_first < 0)
+	dp.state = 2;
+	const size_t vec = std::max((size_t) (A->m + 64), (size_t) std::max<long>(A->n, 1)) * A->vbytes;
+	const size_t pool_bytes = std::min<size_t>(std::max<size_t>((6 * vec + POOL_ALIGN - 1) / POOL_ALIGN * POOL_ALIGN, (size_t) 1 << 30), (size_t) 4 << 30);
+	const size_t budget = budget_bytes(A);
+	Held held;
+	void * cand0 = nullptr;
+	if (hipMalloc(&cand0, pool_bytes) != hipSuccess)
+	{
+		(void) hipGetLastError();
+		return 0;                                  // no room for pools: plain allocations
+	}
+	held.v.push_back(cand0);
+	HIP_TRY(hipMemsetAsync(cand0, 0, pool_bytes, A->stream));
+	HIP_TRY(hipStreamSynchronize(A->stream));
+	const double t0 = kernel_us(A, A->d_x, cand0);
+	if (t0 < 0)
 		return 1;
-	if (w.t_first < 20.0)                  // an (almost) empty handle: nothing a placement could change, nothing to measure it with
-	{
-		w.known = true;
+	if (t0 < 20.0)                                 // launch-bound: differences between blocks drown in the noise
 		return 0;
-	}
-	std::vector<void *> held;              // ballast and rejected candidates, returned at the end
-	w.known = A->place_fast_us > 0 && w.t_first <= A->place_fast_us * CONTRAST;
-	if (!w.known && A->place_only_us > 0 && A->place_fast_us == 0)
+	void * other = nullptr;
+	double t_other = 0;
+	int tries = 1;
+	for (size_t walked = 0; walked + WALK_STEP <= budget && !other; walked += WALK_STEP)
 	{
-		if (w.t_first * CONTRAST < A->place_only_us)       // faster than everything a whole walk saw
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < WALK_STEP + pool_bytes + KEEP_FREE)
+			break;
+		void * ballast = nullptr, * cand = nullptr;
+		if (hipMalloc(&ballast, WALK_STEP) != hipSuccess)
 		{
-			A->place_fast_us = w.t_first;
-			w.known = true;
+			(void) hipGetLastError();
+			break;
 		}
-		else if (w.t_first <= A->place_only_us * CONTRAST)
-			w.known = true;
+		held.v.push_back(ballast);
+		if (hipMalloc(&cand, pool_bytes) != hipSuccess)
+		{
+			(void) hipGetLastError();
+			break;
+		}
+		held.v.push_back(cand);
+		HIP_TRY(hipMemsetAsync(cand, 0, pool_bytes, A->stream));
+		HIP_TRY(hipStreamSynchronize(A->stream));
+		const double t = kernel_us(A, A->d_x, cand);
+		tries++;
+		if (t < 0)
+			return 1;
+		if (verbose())
+			fprintf(stderr, "[spmv_mi355x] placement walk: %.0f GiB in, %.1f us per SpMV (first candidate %.1f us)\n", (double) (walked + WALK_STEP) / (1 << 30), t, t0);
+		if (t * CONTRAST < t0 || t > t0 * CONTRAST)
+		{
+			other = cand;
+			t_other = t;
+		}
 	}
-	if (!w.known)
+	if (other)
 	{
-		bool contrast = false;
-		for (size_t walked = 0; walked < WALK_LIMIT; walked += BALLAST_STEP)
+		// keep the two: take them out of the guard's hands
+		for (void *& p : held.v)
+			if (p == cand0 || p == other)
+				p = nullptr;
+		dp.pool[0].base = (char *) cand0;
+		dp.pool[1].base = (char *) other;
+		for (Pool & p : dp.pool)
 		{
-			size_t free_b = 0, total_b = 0;
-			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < BALLAST_STEP + bytes + KEEP_FREE)
-				break;
-			void * ballast = nullptr, * cand = nullptr;
-			if (hipMalloc(&ballast, BALLAST_STEP) != hipSuccess)
-			{
-				(void) hipGetLastError();
-				break;
-			}
-			held.push_back(ballast);
-			if (hipMalloc(&cand, bytes) != hipSuccess)
-			{
-				(void) hipGetLastError();
-				break;
-			}
-			(void) hipMemset(cand, 0, bytes);
-			(void) hipDeviceSynchronize();
-			const double t = measure(cand);
-			w.tries++;
-			if (t > 0 && t * CONTRAST < w.t_chosen)
-			{
-				if (*chosen != first)
-					held.push_back(*chosen);
-				*chosen = cand;                  // what was held so far shares a block class with the value stream
-				w.t_chosen = t;
-				A->place_fast_us = t;
-				contrast = true;
-				break;
-			}
-			held.push_back(cand);
-			if (t > w.t_chosen * CONTRAST)          // what is held so far is well placed
-			{
-				A->place_fast_us = w.t_chosen;
-				contrast = true;
-				break;
-			}
+			p.size = pool_bytes;
+			p.free_list.assign(1, std::make_pair((size_t) 0, pool_bytes));
+			p.live.clear();
 		}
-		if (!contrast && A->place_fast_us == 0)
-			A->place_only_us = w.t_first;
+		dp.state = 1;
 	}
-	for (void * p : held)
-		(void) hipFree(p);
-	w.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+	held.release();
+	if (verbose())
+		fprintf(stderr, "[spmv_mi355x] placement: device %d, %d candidate(s), %s, pools of %.0f MiB, %.0f ms\n", A->device, tries,
+				other ? "two block classes found" : "no contrast inside the budget: plain allocations", (double) pool_bytes / (1 << 20),
+				std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3);
+	if (other && verbose())
+		fprintf(stderr, "[spmv_mi355x] placement: y in pool 0: %.1f us, in pool 1: %.1f us per SpMV of %s\n", t0, t_other, A->format_name);
 	return 0;
 }
 
-void
-report(const char * what, size_t bytes, const Walk & w)
+int
+plain_alloc(void ** out, size_t bytes)
 {
-	if (setting() >= 2)
-		fprintf(stderr, "[spmv_mi355x] placed %s (%.0f MiB): %.1f us per SpMV on the first candidate, %.1f us on the chosen one, %d candidate(s)%s, %.0f ms\n",
-				what, (double) bytes / (1 << 20), w.t_first, w.t_chosen, w.tries, w.known ? " (rate already known)" : "", w.seconds * 1e3);
+	if (dev_alloc_bytes(out, bytes))
+		return 1;
+	HIP_TRY(hipMemset(*out, 0, std::max<size_t>(bytes, 8)));
+	HIP_TRY(hipDeviceSynchronize());
+	return 0;
 }
 
-// Diagnostic (SPMV_MI355X_PLACEMENT=4): the kernel time with the value array at arena + a*16 GiB and y at arena + (b*16 + 8) GiB
-// of one 160 GiB allocation, a, b = 0..9 — the table of profiles/r02_placement.md §4
+// Diagnostic (level 4): the kernel time with the value array at arena + a*16 GiB and y at arena + (b*16 + 8) GiB of one 160 GiB
+// allocation, a, b = 0..9 — the table of profiles/r02_placement.md §4
 int
 placement_map(spmv_mi355x_matrix * A)
 {
@@ -151,15 +263,21 @@ placement_map(spmv_mi355x_matrix * A)
 	}
 	const size_t G = (size_t) 1 << 30;
 	const int NA = 10;
+	Held held;
 	void * arena = nullptr;
 	HIP_TRY(hipMalloc(&arena, NA * 16 * G));
+	held.v.push_back(arena);
 	void * val0 = A->d_val;
 	fprintf(stderr, "[spmv_mi355x] rows: value array (%.1f GiB) at a*16 GiB; columns: y at b*16+8 GiB; kernel us\n", (double) vsize / G);
 	for (int a = 0; a < NA; a++)
 	{
 		void * v = (char *) arena + (size_t) a * 16 * G;
-		HIP_TRY(hipMemcpy(v, val0, vsize, hipMemcpyDeviceToDevice));
-		HIP_TRY(hipDeviceSynchronize());
+		if (hipMemcpy(v, val0, vsize, hipMemcpyDeviceToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+		{
+			A->d_val = val0;
+			set_error("placement map: device copy failed");
+			return 1;
+		}
 		A->d_val = v;
 		fprintf(stderr, "[spmv_mi355x] a=%d:", a);
 		for (int b = 0; b < NA; b++)
@@ -167,30 +285,25 @@ placement_map(spmv_mi355x_matrix * A)
 		fprintf(stderr, "\n");
 	}
 	A->d_val = val0;
-	HIP_TRY(hipFree(arena));
 	return 0;
 }
 
-}   // namespace
-
-// Coordinate descent over WHERE the handle's arrays live: every array of 16 MiB .. 8 GiB (the value stream first, then y, x, index
-// bytes, row permutation, ...; larger arrays stay and the others are placed against them) is tried at up to ten sites taken 16 GiB apart
-// (a D2D copy and six launches per trial) and stays at the site where the handle's kernel ran fastest, if that beats where it
-// was by 2 %. Sites that end up unused, the ballast between them and the originals of moved arrays are returned.
+// Level 3: coordinate descent over where the handle's MATRIX arrays live (round 2's search, minus the vectors, which the pools place):
+// every array of 16 MiB .. 8 GiB is tried at up to ten sites taken 16 GiB apart (a D2D copy and six launches per trial) and stays
+// where the handle's kernel ran fastest, if that beats where it was by 2 %. Sites that end up unused, the ballast between them and the
+// originals of moved arrays are returned — by the guard on every way out.
 int
-tune_placement(spmv_mi355x_matrix * A)
+search_arrays(spmv_mi355x_matrix * A)
 {
-	if (setting() == 0 || A->placement_off || !A->d_x || !A->d_y || (size_t) (A->m + 64) * A->vbytes < PLACE_MIN_BYTES)
-		return 0;
 	const auto c0 = std::chrono::steady_clock::now();
-	struct Slot { void ** p; const char * name; size_t size, off; };
-	// every device array a kernel READS that can reach 16 MiB, plus the handle's own vectors (keep in step with handle.hpp; an array
-	// missing here simply stays where it is)
-	Slot all[] = {{&A->d_y, "y", 0, 0}, {&A->d_x, "x", 0, 0}, {&A->d_val, "val", 0, 0}, {(void **) &A->d_sell_idx, "sell_idx", 0, 0},
-	              {(void **) &A->d_col, "col", 0, 0}, {(void **) &A->d_row_of_sorted, "row_of_sorted", 0, 0}, {(void **) &A->d_coob_ent, "coob_ent", 0, 0},
-	              {(void **) &A->d_row_ptr, "row_ptr", 0, 0}, {(void **) &A->d_col16, "col16", 0, 0}, {(void **) &A->d_sell_desc, "sell_desc", 0, 0},
-	              {(void **) &A->d_slice_ptr, "slice_ptr", 0, 0}, {(void **) &A->d_rowind, "rowind", 0, 0}};
-	size_t largest = 0;
+	struct Slot { void ** p; const char * name; size_t size; };
+	Slot all[] = {{&A->d_val, "val", 0}, {(void **) &A->d_sell_idx, "sell_idx", 0}, {(void **) &A->d_col, "col", 0},
+	              {(void **) &A->d_row_of_sorted, "row_of_sorted", 0}, {(void **) &A->d_coob_ent, "coob_ent", 0}, {(void **) &A->d_row_ptr, "row_ptr", 0},
+	              {(void **) &A->d_col16, "col16", 0}, {(void **) &A->d_sell_desc, "sell_desc", 0}, {(void **) &A->d_slice_ptr, "slice_ptr", 0},
+	              {(void **) &A->d_rowind, "rowind", 0}};
+	const size_t cap = (size_t) 8 << 30;
+	std::vector<Slot *> movable;
+	size_t site_bytes = 0;
 	for (Slot & sl : all)
 		if (*sl.p)
 		{
@@ -199,37 +312,20 @@ tune_placement(spmv_mi355x_matrix * A)
 				(void) hipGetLastError();
 				sl.size = 0;
 			}
-			largest = std::max(largest, sl.size);
+			if (sl.size >= ((size_t) 16 << 20) && sl.size <= cap)
+			{
+				site_bytes += (sl.size + POOL_ALIGN - 1) / POOL_ALIGN * POOL_ALIGN;
+				movable.push_back(&sl);
+			}
 		}
-	std::vector<Slot *> movable;
-	size_t site_bytes = 0;
-	bool anchored = false;
-	// arrays above the cap stay where they are (the others are placed against them). 8 GiB: the headline's 5.7 GiB value array takes part
-	// (worth 1-2 %: 1.264-1.270 against 1.280-1.294 ms); the sites and the ballast between them still add up to ~160 GiB
-	static const size_t cap = getenv("SPMV_MI355X_PLACEMENT_CAP_GIB") ? (size_t) atol(getenv("SPMV_MI355X_PLACEMENT_CAP_GIB")) << 30 : (size_t) 8 << 30;
-	for (Slot & sl : all)
-	{
-		if (sl.size == largest && !anchored && sl.p != &A->d_y && sl.p != &A->d_x && sl.size > cap)
-		{
-			anchored = true;                        // the big stream everything else is placed against
-			continue;
-		}
-		if (sl.size >= ((size_t) 16 << 20) && sl.size <= cap)
-		{
-			sl.off = site_bytes;
-			site_bytes += (sl.size + ((size_t) 2 << 20) - 1) / ((size_t) 2 << 20) * ((size_t) 2 << 20);
-			movable.push_back(&sl);
-		}
-	}
 	if (movable.empty())
 		return 0;
-	std::stable_sort(movable.begin(), movable.end(), [&](const Slot * a, const Slot * b) { return (a->size == largest) > (b->size == largest); });
-	const size_t ballast_bytes = site_bytes + ((size_t) 1 << 30) < BALLAST_STEP ? BALLAST_STEP - site_bytes : (size_t) 1 << 30;
-	// a site = one buffer per movable array, allocated back to back behind its ballast (so they share a block of HBM); every buffer
-	// is an allocation of its own: what an array does not move into is returned one by one at the end
-	std::vector<void *> ballast;
+	std::stable_sort(movable.begin(), movable.end(), [](const Slot * a, const Slot * b) { return a->size > b->size; });
+	const size_t ballast_bytes = site_bytes + ((size_t) 1 << 30) < WALK_STEP ? WALK_STEP - site_bytes : (size_t) 1 << 30;
+	const size_t budget = budget_bytes(A);
+	Held ballast, rejected;
 	std::vector<std::vector<void *>> sites;
-	for (int s = 0; s < 10; s++)
+	for (size_t s = 0, used = 0; s < 10 && used + ballast_bytes + site_bytes <= budget + WALK_STEP; s++, used += ballast_bytes + site_bytes)
 	{
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < ballast_bytes + site_bytes + KEEP_FREE)
@@ -240,7 +336,7 @@ tune_placement(spmv_mi355x_matrix * A)
 			(void) hipGetLastError();
 			break;
 		}
-		ballast.push_back(b);
+		ballast.v.push_back(b);
 		std::vector<void *> bufs(movable.size(), nullptr);
 		bool ok = true;
 		for (size_t k = 0; k < movable.size() && ok; k++)
@@ -249,125 +345,181 @@ tune_placement(spmv_mi355x_matrix * A)
 				(void) hipGetLastError();
 				ok = false;
 			}
+		for (void * q : bufs)
+			if (q)
+				rejected.v.push_back(q);               // the guard owns every site buffer until an array moves in
 		if (!ok)
-		{
-			for (void * q : bufs)
-				if (q)
-					(void) hipFree(q);
 			break;
-		}
 		sites.push_back(bufs);
 	}
-	const double ms_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3;
-	std::vector<void *> original(movable.size());
-	for (size_t k = 0; k < movable.size(); k++)
-		original[k] = *movable[k]->p;
 	double t_cur = kernel_us(A, A->d_x, A->d_y);
 	const double t_start = t_cur;
-	int rc = t_cur < 0;
-	const std::vector<std::vector<void *>> all_sites = sites;          // for the clean-up at the end
-	if (t_cur >= 0 && t_cur < 20.0)
-		sites.clear();                     // launch-bound: differences between sites drown in the noise
-	// Two sweeps: what is best for y depends on where x and the index arrays end up (and the other way round)
-	for (int sweep = 0, moved_any = 1; sweep < 2 && moved_any && !rc && !sites.empty(); sweep++)
+	if (t_cur < 0)
+		return 1;
+	if (t_cur < 20.0)
+		return 0;
+	for (int sweep = 0, moved_any = 1; sweep < 2 && moved_any && !sites.empty(); sweep++)
 	{
 		moved_any = 0;
-		for (size_t k = 0; k < movable.size() && !rc; k++)
+		for (size_t k = 0; k < movable.size(); k++)
 		{
 			Slot * sl = movable[k];
 			void * const orig = *sl->p;
 			int best = -1;
 			double t_best = t_cur;
-			if (setting() >= 2)
+			if (verbose())
 				fprintf(stderr, "[spmv_mi355x] %-14s %5.0f MiB: %7.1f us where it is; at the sites:", sl->name, (double) sl->size / (1 << 20), t_cur);
-			for (size_t s = 0; s < sites.size() && !rc; s++)
+			for (size_t s = 0; s < sites.size(); s++)
 			{
 				void * dst = sites[s][k];
-				if (dst == orig)                          // second sweep: the site it already lives at
-				{
-					if (setting() >= 2)
-						fprintf(stderr, " =");
+				if (dst == orig)
 					continue;
-				}
 				// on the stream the trial launches use, and finished before they start: a kernel that read a half-copied index
 				// array would gather x out of bounds
 				if (hipMemcpyAsync(dst, orig, sl->size, hipMemcpyDeviceToDevice, A->stream) != hipSuccess || hipStreamSynchronize(A->stream) != hipSuccess)
 				{
+					*sl->p = orig;
 					set_error("placement: device copy failed: %s", hipGetErrorString(hipGetLastError()));
-					rc = 1;
-					break;
+					return 1;
 				}
 				*sl->p = dst;
 				const double t = kernel_us(A, A->d_x, A->d_y);
+				*sl->p = orig;
 				if (t < 0)
-					rc = 1;
-				if (setting() >= 2)
+					return 1;
+				if (verbose())
 					fprintf(stderr, " %.0f", t);
-				if (t > 0 && t < t_best * 0.98)
+				if (t < t_best * 0.98)
 				{
 					best = (int) s;
 					t_best = t;
 				}
 			}
-			if (best >= 0 && !rc)
+			if (best >= 0)
 			{
-				// every site holds a faithful copy: the arrays the kernel reads never change, y is zeroed below
-				*sl->p = sites[(size_t) best][k];
+				// the array moves in: the site buffer leaves the guard, the old home enters it
+				void * const now = sites[(size_t) best][k];
+				for (void *& q : rejected.v)
+					if (q == now)
+						q = orig;
+				*sl->p = now;
 				t_cur = t_best;
 				moved_any = 1;
 			}
-			else
-				*sl->p = orig;
-			if (setting() >= 2)
+			if (verbose())
 				fprintf(stderr, " -> %s, %.1f us\n", best >= 0 ? "moved" : "stays", t_cur);
 		}
 	}
-	if (!rc)
-		HIP_TRY(hipMemset(A->d_y, 0, (size_t) (A->m + 64) * A->vbytes));
 	HIP_TRY(hipDeviceSynchronize());
-	for (void * p : ballast)
-		(void) hipFree(p);
-	// every site buffer an array did not end up in goes back, and so does the original of an array that moved: each array is again
-	// an allocation of its own, owned through the handle's pointer as before
-	for (size_t k = 0; k < movable.size(); k++)
-	{
-		void * const now = *movable[k]->p;
-		for (const auto & bufs : all_sites)
-			if (bufs[k] != now)
-				(void) hipFree(bufs[k]);
-		if (original[k] != now)
-			(void) hipFree(original[k]);
-	}
-	A->place_fast_us = t_cur;                      // later output vectors are held against this
-	if (setting() >= 2)
-		fprintf(stderr, "[spmv_mi355x] placement: %.1f -> %.1f us per SpMV, %zu sites, %.0f ms (%.0f ms of it allocating the sites)\n", t_start, t_cur,
-				all_sites.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3, ms_alloc);
-	if (!rc && setting() == 4)
-		return placement_map(A);
-	return rc;
+	if (verbose())
+		fprintf(stderr, "[spmv_mi355x] array search: %.1f -> %.1f us per SpMV, %zu sites, %.0f ms\n", t_start, t_cur, sites.size(),
+				std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3);
+	return 0;
 }
 
-// allocation of `bytes` for a vector the handle's SpMV writes (A->d_x must exist). Zero-filled.
+}   // namespace
+
+// A zero-filled device vector of `bytes` for handle A: one its SpMV WRITES (is_output: timed as y against A's x) or one it READS (timed
+// as x against A's y). With placement on and the vector large enough it is a slice of the device's pool in which A's kernel runs faster.
 int
-dev_alloc_output(spmv_mi355x_matrix * A, void ** out, size_t bytes)
+place_vector(spmv_mi355x_matrix * A, void ** out, size_t bytes, bool is_output)
 {
-	if (dev_alloc_bytes(out, bytes))
-		return 1;
-	HIP_TRY(hipMemset(*out, 0, std::max<size_t>(bytes, 8)));
-	HIP_TRY(hipDeviceSynchronize());
-	const size_t need = (size_t) (A->m + 64) * A->vbytes;
-	if (setting() == 0 || A->placement_off || bytes < PLACE_MIN_BYTES || bytes < need || !A->d_x)
+	*out = nullptr;
+	const size_t need = is_output ? (size_t) (A->m + 64) * A->vbytes : (size_t) std::max<long>(A->n, 1) * A->vbytes;
+	const void * other = is_output ? (const void *) A->d_x : (const void *) A->d_y;
+	if (level_of(A) < 1 || bytes < PLACE_MIN_BYTES || bytes < need || !other || A->device < 0 || A->device >= MAX_DEV)
+		return plain_alloc(out, bytes);
+	std::lock_guard<std::mutex> lock(g_mu);
+	DevPools & dp = g_dev[A->device];
+	if (dp.state == 0)
+	{
+		if (!is_output || !A->d_x)
+			return plain_alloc(out, bytes);            // the walk is made with a y candidate
+		if (build_pools(A, dp))
+			return 1;
+	}
+	if (dp.state != 1)
+		return plain_alloc(out, bytes);
+	void * c[2] = {pool_alloc(dp.pool[0], bytes), pool_alloc(dp.pool[1], bytes)};
+	if (!c[0] || !c[1])
+	{
+		for (int k = 0; k < 2; k++)
+			if (c[k])
+				pool_free(dp.pool[k], c[k]);
+		return plain_alloc(out, bytes);                // pools exhausted
+	}
+	double t[2];
+	for (int k = 0; k < 2; k++)
+	{
+		HIP_TRY(hipMemsetAsync(c[k], 0, bytes, A->stream));
+		HIP_TRY(hipStreamSynchronize(A->stream));
+		t[k] = is_output ? kernel_us(A, A->d_x, c[k]) : kernel_us(A, c[k], A->d_y);
+		if (t[k] < 0)
+			return 1;
+	}
+	const int win = t[1] < t[0] ? 1 : 0;
+	pool_free(dp.pool[1 - win], c[1 - win]);
+	if (is_output)
+	{
+		HIP_TRY(hipMemsetAsync(c[win], 0, bytes, A->stream));      // the trials wrote into it
+		HIP_TRY(hipStreamSynchronize(A->stream));
+	}
+	*out = c[win];
+	if (verbose())
+		fprintf(stderr, "[spmv_mi355x] placed %s of %s (%.0f MiB): %.1f / %.1f us per SpMV in pool 0 / 1 -> pool %d\n", is_output ? "an output vector" : "an input vector",
+				A->format_name, (double) bytes / (1 << 20), t[0], t[1], win);
+	return 0;
+}
+
+// frees what place_vector (or a plain allocation) returned
+int
+vector_free(void * p)
+{
+	if (!p)
 		return 0;
-	void * first = *out, * chosen = nullptr;
-	Walk w;
-	if (walk(A, first, bytes, [&](void * c) { return kernel_us(A, A->d_x, c); }, &chosen, w))
+	{
+		std::lock_guard<std::mutex> lock(g_mu);
+		for (DevPools & dp : g_dev)
+			if (dp.state == 1)
+				for (Pool & pl : dp.pool)
+					if (pool_free(pl, p))
+						return 0;
+	}
+	HIP_TRY(hipFree(p));
+	return 0;
+}
+
+// Once per handle, when its own x / y pair is first needed (A->d_x exists as a plain, zeroed allocation): y into the better pool, then x.
+int
+tune_placement(spmv_mi355x_matrix * A)
+{
+	if (place_vector(A, &A->d_y, (size_t) (A->m + 64) * A->vbytes, true))
 		return 1;
-	if (chosen != first)
-		HIP_TRY(hipFree(first));
-	HIP_TRY(hipMemset(chosen, 0, bytes));
-	HIP_TRY(hipDeviceSynchronize());
-	*out = chosen;
-	report("an output vector", bytes, w);
+	if (level_of(A) < 1)
+		return 0;
+	void * x2 = nullptr;
+	const size_t xb = (size_t) std::max<long>(A->n, 1) * A->vbytes;
+	if (place_vector(A, &x2, xb, false))
+		return 1;
+	// x2 is a pool slice only when the pools exist and x is large enough; otherwise it is one more plain allocation: keep the first
+	bool pooled = false;
+	{
+		std::lock_guard<std::mutex> lock(g_mu);
+		const DevPools & dp = g_dev[std::min(std::max(A->device, 0), MAX_DEV - 1)];
+		for (const Pool & pl : dp.pool)
+			pooled = pooled || (dp.state == 1 && pl.base && (char *) x2 >= pl.base && (char *) x2 < pl.base + pl.size);
+	}
+	if (pooled)
+	{
+		(void) hipFree(A->d_x);
+		A->d_x = x2;
+	}
+	else if (vector_free(x2))
+		return 1;
+	if (level_of(A) >= 3 && search_arrays(A))
+		return 1;
+	if (level_of(A) >= 4)
+		return placement_map(A);
 	return 0;
 }
 
@@ -384,16 +536,62 @@ spmv_mi355x_output_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out)
 		return 1;
 	}
 	*out = nullptr;
-	if (spmv::ensure_x(A))                   // sets the device, creates the handle's stream and its own x
+	if (spmv::ensure_x(A))                   // sets the device, creates the handle's own x
 		return 1;
-	return spmv::dev_alloc_output(A, out, bytes);
+	return spmv::place_vector(A, out, bytes, true);
+}
+
+int
+spmv_mi355x_input_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out)
+{
+	if (!A || !out)
+	{
+		spmv::set_error("input_alloc: NULL argument");
+		return 1;
+	}
+	*out = nullptr;
+	if (!spmv_mi355x_y_device(A))            // the handle's own pair first: an input vector is timed against the handle's y
+		return 1;
+	return spmv::place_vector(A, out, bytes, false);
 }
 
 int
 spmv_mi355x_output_free(void * p)
 {
-	if (p)
-		HIP_TRY(hipFree(p));
+	return spmv::vector_free(p);
+}
+
+int
+spmv_mi355x_placement_release(int device)
+{
+	std::lock_guard<std::mutex> lock(spmv::g_mu);
+	for (int d = 0; d < spmv::MAX_DEV; d++)
+	{
+		if (device >= 0 && d != device)
+			continue;
+		spmv::DevPools & dp = spmv::g_dev[d];
+		if (dp.state != 1)
+		{
+			dp.state = 0;
+			continue;
+		}
+		if (!dp.pool[0].live.empty() || !dp.pool[1].live.empty())
+		{
+			spmv::set_error("placement_release: device %d still has %zu vector(s) in its pools", d, dp.pool[0].live.size() + dp.pool[1].live.size());
+			return 1;
+		}
+		int cur = -1;
+		(void) hipGetDevice(&cur);
+		(void) hipSetDevice(d);
+		for (spmv::Pool & pl : dp.pool)
+		{
+			(void) hipFree(pl.base);
+			pl = spmv::Pool();
+		}
+		if (cur >= 0)
+			(void) hipSetDevice(cur);
+		dp.state = 0;
+	}
 	return 0;
 }
 

@@ -26,7 +26,8 @@ init_handle(spmv_mi355x_matrix * A, int format, int precision, int device, const
 	A->f32 = (precision == SPMV_MI355X_F32);
 	A->vbytes = A->f32 ? 4 : 8;
 	A->device = device;
-	A->placement_off = o.placement == 2;
+	A->placement_level = (o.placement == 1 || o.placement == 3 || o.placement == 4) ? o.placement : 0;      // 0 and 2: off
+	A->placement_budget_gib = o.placement_budget_gib > 0 ? o.placement_budget_gib : 0;
 	A->n = n;
 	A->m = m;
 	A->nnz = nnz;
@@ -324,15 +325,8 @@ ensure_xy(spmv_mi355x_matrix * A)
 		return 1;
 	if (!A->stream)
 		HIP_TRY(hipStreamCreate(&A->stream));          // a BLOCKING stream: ordered against the null-stream copies / fills of create() and of placement
-	if (!A->d_y)
-	{
-		if (dev_alloc_bytes(&A->d_y, (size_t) (A->m + 64) * A->vbytes))
-			return 1;
-		HIP_TRY(hipMemset(A->d_y, 0, (size_t) (A->m + 64) * A->vbytes));
-		HIP_TRY(hipDeviceSynchronize());
-		if (tune_placement(A))              // placement.hip: once, now that every array of the handle exists
-			return 1;
-	}
+	if (!A->d_y && tune_placement(A))       // placement.hip: y (zero-filled), plain or from the device's vector pools; x re-homed with it
+		return 1;
 	return 0;
 }
 

@@ -142,45 +142,6 @@ def _chunks(lens, max_nnz):
     return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
-def _place_input(torch, M, count, t_dtype, y_ptr, sp):
-    """A zeroed device vector of `count` values for handle M to READ as x, placed the way the engine places the vectors it owns
-    (csrc/placement.hip; here x must be a torch tensor because the collectives write into it): candidates are taken from deeper
-    and deeper in the pool, 16 GiB of ballast apart, until one is 4 % faster or slower than the first under M's own kernel (y given).
-    Everything but the winner goes back to the driver."""
-    first = torch.zeros(count, dtype=t_dtype, device="cuda")
-    nbytes = first.numel() * first.element_size()
-    if nbytes < (8 << 20) or os.environ.get("SPMV_MI355X_PLACEMENT") == "0":
-        return first
-
-    def measure(x):
-        M.time_device(x.data_ptr(), y_ptr, 2, sp)
-        return M.time_device(x.data_ptr(), y_ptr, 4, sp)
-
-    best_t, best, held = measure(first), first, []
-    if best_t < 0.02:                                   # an (almost) empty handle: nothing to measure with
-        return first
-    step = 16 << 30
-    for _ in range(10):
-        if torch.cuda.mem_get_info()[0] < step + nbytes + (8 << 30):
-            break
-        try:
-            held.append(torch.empty(step, dtype=torch.uint8, device="cuda"))
-            cand = torch.zeros(count, dtype=t_dtype, device="cuda")
-        except RuntimeError:
-            break
-        t = measure(cand)
-        if t * 1.04 < best_t:
-            held.append(best)
-            best_t, best = t, cand
-            break
-        held.append(cand)
-        if t > best_t * 1.04:
-            break
-    del held
-    torch.cuda.empty_cache()
-    return best
-
-
 def _streamable(c, pieces):
     """Several pieces become ONE handle through the engine's device-resident CSR stream when the format allows it (SELL-64 delta
     layout, what sell_c_sigma picks for matrices of this size); otherwise every piece becomes its own handle."""
@@ -300,7 +261,8 @@ class RowsVariant:
         del touched
         self.y_vec = self.mats[0].output_vector(lm + 64)        # placed by the engine relative to the handle's arrays (csrc/placement.hip)
         self.y = self.y_vec.torch()
-        self.x_full = _place_input(torch, self.mats[0], self.n_x, c.t_dtype, self.y.data_ptr(), c.sp)      # ... and x the same way
+        self.x_vec = self.mats[0].input_vector(self.n_x)        # ... and x the same way (a zero-copy torch view: the collectives write into it)
+        self.x_full = self.x_vec.torch()
         self.y.fill_(1.0)
         self.x_loc = self.x_full[c.rank * self.padded:(c.rank + 1) * self.padded]       # in-place allgather: own slice lives inside x_full
         self._fill_own()
@@ -522,7 +484,8 @@ class GraphVariant:
         self.t_conv = time.time() - t0
         self.y_vec = self.mats[0].output_vector(self.lm + 64)   # placed by the engine relative to the first block's arrays
         self.y = self.y_vec.torch()
-        x_new = _place_input(torch, self.mats[0], n, c.t_dtype, self.y.data_ptr(), c.sp)           # ... and x the same way
+        self.x_vec = self.mats[0].input_vector(n)               # ... and x the same way (zero-copy torch view)
+        x_new = self.x_vec.torch()
         x_new.copy_(self.x_full)
         self.x_full = self.packed.x_full = x_new         # the exchange scatters into / packs from the vector it is handed
         self.y.fill_(1.0)
@@ -652,6 +615,7 @@ def run(args, B):
     c.t_dtype = torch.float64 if c.dts == "f64" else torch.float32
     c.vbytes = 8 if c.dts == "f64" else 4
     c.opts = B.collect_opts(args, workload)
+    c.opts.setdefault("placement", 1)        # vectors from the engine's pools (csrc/placement.hip): opt-in, and the bench opts in
     c.sp = torch.cuda.current_stream().cuda_stream
     t0 = time.time()
     c.src = Source(H, B, workload, args.scale)

@@ -27,7 +27,8 @@ class Opts(C.Structure):
                 ("row_begin", C.c_long), ("row_end", C.c_long), ("col_begin", C.c_long), ("col_end", C.c_long),
                 ("col_filter_mode", C.c_int), ("sell_delta", C.c_int), ("convert_on", C.c_int),
                 ("symmetric_input", C.c_int), ("rows_per_group", C.c_int), ("col_blocks", C.c_int),
-                ("sell_window", C.c_int), ("kahan", C.c_int), ("sell_group", C.c_int), ("placement", C.c_int)]
+                ("sell_window", C.c_int), ("kahan", C.c_int), ("sell_group", C.c_int), ("placement", C.c_int),
+                ("placement_budget_gib", C.c_int)]
 
 
 # every symbol declared in include/spmv_mi355x.h (checked by tests/test_abi.py)
@@ -44,7 +45,7 @@ SYMBOLS = [
     "spmv_mi355x_partitioned_set_always_copy", "spmv_mi355x_time_partitioned", "spmv_mi355x_partitioned_parts",
     "spmv_mi355x_partitioned_offsets", "spmv_mi355x_partitioned_format_name", "spmv_mi355x_partitioned_exchange",
     "spmv_mi355x_partitioned_mem_footprint",
-    "spmv_mi355x_upload_y", "spmv_mi355x_output_alloc", "spmv_mi355x_output_free",
+    "spmv_mi355x_upload_y", "spmv_mi355x_output_alloc", "spmv_mi355x_input_alloc", "spmv_mi355x_output_free", "spmv_mi355x_placement_release",
     "spmv_mi355x_csr_stream_begin", "spmv_mi355x_csr_stream_append", "spmv_mi355x_create_from_stream", "spmv_mi355x_csr_stream_discard",
 ]
 
@@ -88,6 +89,11 @@ def _check(rc):
         raise SpmvError(lib().spmv_mi355x_last_error().decode())
 
 
+def placement_release(device=-1):
+    """Free the vector pools of a device (-1: all) — no vector of them may be live (include/spmv_mi355x.h)."""
+    _check(lib().spmv_mi355x_placement_release(C.c_int(device)))
+
+
 def device_count():
     c = C.c_int()
     _check(lib().spmv_mi355x_device_count(C.byref(c)))
@@ -111,11 +117,12 @@ class OutputVector:
     engine"): placed by timing the handle's own kernel on it. `.ptr` goes to spmv_device(); `.torch()` is a zero-copy torch
     view (CUDA array interface) for callers that fill / check it with torch."""
 
-    def __init__(self, matrix, count):
+    def __init__(self, matrix, count, is_input=False):
         self.count, self.dtype = int(count), np.dtype(matrix.dtype)
         self.nbytes = max(self.count, 1) * self.dtype.itemsize
         out = C.c_void_p()
-        _check(lib().spmv_mi355x_output_alloc(matrix.h, C.c_size_t(self.nbytes), C.byref(out)))
+        alloc = lib().spmv_mi355x_input_alloc if is_input else lib().spmv_mi355x_output_alloc
+        _check(alloc(matrix.h, C.c_size_t(self.nbytes), C.byref(out)))
         self.ptr = out.value
         self._view = None
 
@@ -363,6 +370,11 @@ class Matrix:
     def output_vector(self, count=None):
         """An engine-placed device vector for this handle's SpMV to write (rows + 64 values by default)."""
         return OutputVector(self, self.m + 64 if count is None else count)
+
+    def input_vector(self, count=None):
+        """An engine-placed device vector for this handle's SpMV to READ as x (cols values by default); `.torch()` gives the zero-copy
+        tensor a collective can write into."""
+        return OutputVector(self, self.n if count is None else count, is_input=True)
 
     def upload_y(self, y):
         y = np.ascontiguousarray(y, self.dtype)

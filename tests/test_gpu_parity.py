@@ -586,7 +586,7 @@ def test_merge_drops_the_value_stream_of_pattern_matrices(eng, oracle):
 
 def test_engine_placed_vectors(eng, oracle):
     """The handle's own x / y pair and an output vector from output_alloc (csrc/placement.hip): results through them equal the
-    host-buffer path; y += A x through upload_y. Small matrix: no placement search (below 32 MiB), only the plumbing."""
+    host-buffer path; y += A x through upload_y. Small matrix: no placement (below 8 MiB, and not asked for), only the plumbing."""
     info, g = load_case("general_real")
     rp, ci, a = g["row_ptr"], g["col_idx"], g["values"]
     m, n = info["m"], info["n"]
@@ -612,8 +612,9 @@ def test_engine_placed_vectors(eng, oracle):
 
 
 def test_placement_search_keeps_results(eng):
-    """A matrix whose y is above the 32 MiB threshold: the placement pass runs (y, x, the index arrays are tried at other sites
-    and may move) and an output vector is placed against the tuned handle; results must not change."""
+    """A matrix whose y is above the 8 MiB threshold, placement asked for (opts.placement = 1): the first handle walks the device's
+    free memory for the two vector pools, its vectors and a caller's output / input vectors are pool slices; results must not change,
+    the pools outlive the handle and go when asked."""
     m = 4_600_000
     rp = np.arange(0, 3 * m + 1, 3, dtype=np.int32)
     rows = np.arange(m, dtype=np.int64)
@@ -622,18 +623,34 @@ def test_placement_search_keeps_results(eng):
     ci[-1] = [m - 3, m - 2, m - 1]
     ci = ci.reshape(-1).astype(np.int32)
     a = np.tile(np.array([0.5, 2.0, -0.25]), m)
-    A = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma")
+    A = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma", placement=1, placement_budget_gib=64)
     x = np.random.default_rng(7).uniform(-1, 1, m)
-    v = A.output_vector()                                # before the handle's own pass (only its zeroed x exists)
-    y = A.spmv(x)                                        # runs the placement pass, uploads x
+    v = A.output_vector()                                # before the handle's own pair exists (only its zeroed x): makes the walk
+    y = A.spmv(x)                                        # places the handle's y and x, uploads x
     ref = 0.5 * x[ci[0::3]] + 2.0 * x[ci[1::3]] - 0.25 * x[ci[2::3]]
     np.testing.assert_allclose(y, ref, rtol=1e-13, atol=1e-13)
     A.spmv_device(A.x_device(), v.ptr, 0, 0)
     import torch
     torch.cuda.synchronize()
     np.testing.assert_allclose(v.torch()[:m].cpu().numpy(), ref, rtol=1e-13, atol=1e-13)
+    xin = A.input_vector()                               # a vector the kernel READS, e.g. the x a collective fills
+    xin.torch().copy_(torch.from_numpy(x).cuda())
+    A.spmv_device(xin.ptr, v.ptr, 0, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(v.torch()[:m].cpu().numpy(), ref, rtol=1e-13, atol=1e-13)
+    B = eng.Matrix(rp, ci, a, m, m, "csr_vector", placement=1)      # a second handle: no walk, slices of the same pools
+    np.testing.assert_allclose(B.spmv(x), ref, rtol=1e-12, atol=1e-12)
+    B.close()
     v.free()
+    xin.free()
     A.close()
+    eng.placement_release()                              # nothing of the pools is live any more
+    # default: placement off — plain allocations, nothing held behind the handle's back
+    free0 = torch.cuda.mem_get_info()[0]
+    A = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma")
+    np.testing.assert_allclose(A.spmv(x), ref, rtol=1e-13, atol=1e-13)
+    A.close()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < (64 << 20)
 
 
 def test_placement_moves_index_arrays_safely(eng, oracle):
@@ -647,7 +664,7 @@ def test_placement_moves_index_arrays_safely(eng, oracle):
     ci = np.minimum(ci, m - 1 - (k - 1 - np.arange(k))).astype(np.int32).reshape(-1)
     rp = np.arange(0, m * k + 1, k, dtype=np.int32)
     a = rng.uniform(-1, 1, m * k)
-    A = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma")
+    A = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma", placement=3, placement_budget_gib=64)      # 3 = pools + the search over the matrix arrays
     x = rng.uniform(-1, 1, m)
     y = A.spmv(x)                                        # first use of the handle's vectors: the placement pass
     sample = rng.integers(0, m, 3000)
@@ -655,6 +672,7 @@ def test_placement_moves_index_arrays_safely(eng, oracle):
     den = np.array([np.dot(np.abs(a[i * k:(i + 1) * k]), np.abs(x[ci[i * k:(i + 1) * k]])) for i in sample])
     assert np.all(np.abs(y[sample] - ref) <= 1e-12 * den)
     A.close()
+    eng.placement_release()
 
 
 def test_handle_from_a_csr_that_arrives_in_pieces(eng, oracle):

@@ -144,3 +144,33 @@ def test_rccl_back_end_with_one_part(eng, oracle):
     y2 = P.spmv(2 * x)
     assert np.all(np.abs(y2 - 2 * y) <= 4e-12 * absrow + 1e-300)
     P.close()
+
+
+@pytest.mark.parametrize("exchange", [0, 1, 2], ids=["auto", "rccl", "peer-copies"])
+def test_parts_on_distinct_devices(eng, oracle, exchange):
+    """The first box with more than one GPU runs what a one-GPU box cannot: parts on DISTINCT devices, ncclCommInitAll over them with
+    the grouped in-place ncclAllGather (exchange 0 / 1) and hipMemcpyPeerAsync (exchange 2); the caller's current device is left as
+    it was by every entry point. Skipped on the one-GPU boxes of the pool."""
+    import torch
+    ndev = eng.device_count()
+    if ndev < 2:
+        pytest.skip("needs at least two GPUs")
+    import spmv_host as H
+    A = H.gen_kkt(16)
+    rp, ci, a, m, n = A["row_ptr"], A["col_idx"], A["values"], A["m"], A["n"]
+    x = np.random.default_rng(21).uniform(-1, 1, n)
+    absrow = oracle.csr_spmv(rp, ci, np.abs(a), np.abs(x))
+    y_ref = oracle.csr_spmv(rp, ci, a, x)
+    nparts = min(ndev, 4)
+    torch.cuda.set_device(ndev - 1)                          # not device 0: a restore to "0" would show
+    P = eng.PartitionedMatrix(rp, ci, a, m, n, nparts, "sell_c_sigma", np.float64, devices=list(range(nparts)), exchange=exchange, sell_split=1)
+    assert torch.cuda.current_device() == ndev - 1
+    assert ("RCCL" in P.exchange) if exchange in (0, 1) else ("cop" in P.exchange)
+    y = P.spmv(x)
+    assert torch.cuda.current_device() == ndev - 1
+    assert np.all(np.abs(y - y_ref) <= 1e-12 * absrow + 1e-300)
+    np.testing.assert_array_equal(y, _emulate(eng, rp, ci, a, m, n, P.offsets, "sell_c_sigma", np.float64, x, sell_split=1))
+    assert P.time(5) > 0 and torch.cuda.current_device() == ndev - 1
+    P.close()
+    assert torch.cuda.current_device() == ndev - 1
+    torch.cuda.set_device(0)
