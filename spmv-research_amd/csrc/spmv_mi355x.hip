@@ -214,6 +214,15 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 	cfg.beta = beta ? 1 : 0;
 	long grid = 0;
 	int rc = 1;
+	if (A->nnz == 0)
+	{
+		// a handle without entries (the remote-column half of a row block whose columns are all local): y += 0 is nothing at all,
+		// y = 0 is a fill — no kernel walks empty slices and no launch re-reads and re-writes y
+		if (!beta && A->m > 0)
+			HIP_TRY(hipMemsetAsync(y, 0, (size_t) A->m * A->vbytes, st));
+		A->last_grid = 0;
+		return 0;
+	}
 	switch (A->format)
 	{
 		case SPMV_MI355X_CSR_SCALAR:
