@@ -577,6 +577,17 @@ def main():
         "check_max_err_over_abs_row": t["check"],
         "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t["convert_s"], 2), "upload_x_place_vectors": round(t["place_s"], 2)},
     }
+    if workload == "nlpkkt240" and fmt == "sell_c_sigma" and not args.index_modes_off and not args.jitter and args.scale == 1.0:
+        # the other end of the headline: the same matrix with every index-free mode of the delta layout switched off (8/16-bit deltas per
+        # lane and step everywhere) — what a matrix without the twin's translation invariance gets from the format
+        os.environ["SPMV_MI355X_SELL_MODES_OFF"] = "7"
+        tf = time_handle(E, torch, A, fmt, dts, opts, min(args.steps, 300), args.warmup, x_host=t["x_host"])
+        del os.environ["SPMV_MI355X_SELL_MODES_OFF"]
+        rf = roofline_record(workload, dts, tf, with_traffic=False)
+        result["roofline"]["frac_floor"] = rf["frac"]
+        result["roofline"]["floor"] = {"what": "index-free modes off (SPMV_MI355X_SELL_MODES_OFF=7)", "ms": rf["ms"], "kernel_ms": rf["kernel_ms"],
+                                       "stored_bytes_per_nnz": round(tf["mem_footprint"] / max(nnz, 1), 3)}
+        del tf
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, workload, dts, A, t["x_host"], t["yh"])
     del A, t

@@ -105,6 +105,31 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 	return 0;
 }
 
+// mode 5 of the delta layout: the EXCEPTION lanes of a slice (64 equally long rows rows[0..63]) — those whose columns are not
+// column_k[reference r] + (first column - reference's first column) at every step — and whether some lane's difference does not fit a
+// signed byte (`hard`): the host twin of sell5_exceptions() in convert_sell.hip
+static unsigned long long
+sell5_exceptions(const int * rp, const int * ci, const int * rows, long maxlen, int r, bool & hard)
+{
+	unsigned long long mask = 0;
+	hard = false;
+	const int * cr = ci + rp[rows[r]];
+	for (int l = 0; l < 64; l++)
+	{
+		const int * cl = ci + rp[rows[l]];
+		const int off = cl[0] - cr[0];
+		for (long k = 1; k < maxlen; k++)
+		{
+			const int d = cl[k] - cr[k] - off;
+			if (d != 0)
+				mask |= 1ull << l;
+			if (d < -128 || d > 127)
+				hard = true;
+		}
+	}
+	return mask;
+}
+
 // SELL-64-sigma-delta build (layout: kernels_sell.hip). Same sigma-window sort and slice widths as build_sell with C = 64,
 // widths padded to a multiple of 4 steps; per slice the narrowest index encoding that holds every (step, lane) delta.
 static int
@@ -205,16 +230,36 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 			if (hi >= 0)
 				maxdelta = std::max<long>(maxdelta, (long) hi - lo);
 		}
-		const int md = (affine && !(sell_modes_off() & 1)) ? 0 : (rowoff && !(sell_modes_off() & 2)) ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
-		mode[sl] = (unsigned char) md;
+		// lane offsets with exceptions (mode 5, kernels_sell.hip): equally long rows, not all of one pattern, but at least 48 of the
+		// 64 agree with one of the first four lanes taken as the reference (the same rule as convert_sell.hip: same bytes)
+		int ref = -1, nex = 0;
+		{
+			bool equal_len = (sl + 1) * C <= m && A->n >= C && maxlen > 0;
+			for (long i = sl * C; i < i_e && equal_len; i++)
+				equal_len = (rp[row_of_sorted[i] + 1] - rp[row_of_sorted[i]]) == maxlen;
+			if (equal_len && !rowoff && !(sell_modes_off() & 4))
+				for (int r = 0; r < 4 && ref < 0; r++)
+				{
+					bool hard;
+					const int e = __builtin_popcountll(sell5_exceptions(rp, ci, row_of_sorted.data() + sl * C, maxlen, r, hard));
+					if (C - e >= 48 && e > 0 && !hard)
+					{
+						ref = r;
+						nex = e;
+					}
+				}
+		}
+		const int md = (affine && !(sell_modes_off() & 1)) ? 0 : (rowoff && !(sell_modes_off() & 2)) ? 3 : ref >= 0 ? 5 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		mode[sl] = (unsigned char) (md == 5 ? (5 | ref << 3) : md);
 		val_ptr[sl + 1] = maxlen * C;                    // values: exact width; index groups: rounded up to 4 steps
-		idx_ptr[sl + 1] = (md == 3 ? 4 * C : 0) + (width / 4) * ((md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024);
+		idx_ptr[sl + 1] = md == 5 ? (4 * C + 16) + (width / 4) * (16 + (nex + 3) / 4 * 16)
+		                          : (md == 3 ? 4 * C : 0) + (width / 4) * ((md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024);
 	}
 	for (long sl = 0; sl < num_slices; sl++)
 	{
 		val_ptr[sl + 1] += val_ptr[sl];
 		idx_ptr[sl + 1] += idx_ptr[sl];
-		A->sell_mode_slices[(mode[sl] == 0 || mode[sl] == 3) ? 3 : mode[sl] == 1 ? 0 : mode[sl] == 2 ? 1 : 2]++;
+		A->sell_mode_slices[((mode[sl] & 7) == 0 || (mode[sl] & 7) == 3 || (mode[sl] & 7) == 5) ? 3 : (mode[sl] & 7) == 1 ? 0 : (mode[sl] & 7) == 2 ? 1 : 2]++;
 	}
 	const int64_t nnz_ext = val_ptr[num_slices];
 	const int64_t idx_bytes = idx_ptr[num_slices];
@@ -227,12 +272,32 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 		const int64_t vb = val_ptr[sl];
 		const long maxlen = (val_ptr[sl + 1] - vb) / C;
 		const long width = (maxlen + 3) / 4 * 4;
-		const int md = mode[sl];
+		const int md = mode[sl] & 7, ref = mode[sl] >> 3;
 		unsigned char * ib = idx.data() + idx_ptr[sl];
 		desc[2 * sl] = vb;
 		desc[2 * sl + 1] = idx_ptr[sl] | md;
 		const long i_e = std::min(m, (sl + 1) * C);
 		int min_off = 0;
+		unsigned long long exmask = 0;
+		int nex = 0;
+		int off5[64];
+		if (md == 5)
+		{
+			// header: the 64 lane offsets relative to the reference lane's first column, the exception mask, padding
+			bool hard;
+			exmask = sell5_exceptions(rp, ci, row_of_sorted.data() + sl * C, maxlen, ref, hard);
+			nex = __builtin_popcountll(exmask);
+			const int oref = row_of_sorted[sl * C + ref];
+			for (int r = 0; r < C; r++)
+			{
+				off5[r] = ci[rp[row_of_sorted[sl * C + r]]] - ci[rp[oref]];
+				reinterpret_cast<int *>(ib)[r] = off5[r];
+				min_off = std::min(min_off, off5[r]);
+			}
+			reinterpret_cast<unsigned long long *>(ib + 4 * C)[0] = exmask;
+			reinterpret_cast<unsigned long long *>(ib + 4 * C)[1] = 0ull;
+			ib += 4 * C + 16;
+		}
 		if (md == 3)
 		{
 			// header: the 64 lane offsets (relative to lane 0's column), then the groups of 4 bases
@@ -258,8 +323,10 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 				base = 0;                              // a step that is padding for every lane
 			if (md == 3)                               // base + off[lane] must be lane 0's column (real step) / a valid column (padding)
 				base = (k < rp[row_of_sorted[sl * C] + 1] - rp[row_of_sorted[sl * C]]) ? ci[rp[row_of_sorted[sl * C]] + k] : -min_off;
+			if (md == 5)                               // ... the reference lane's
+				base = k < maxlen ? ci[rp[row_of_sorted[sl * C + ref]] + k] : -min_off;
 			const long g = k / 4, u = k % 4;
-			const long gbytes = (md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
+			const long gbytes = md == 5 ? 16 + (nex + 3) / 4 * 16 : (md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
 			unsigned char * gp = ib + g * gbytes;
 			if (md != 4)
 				reinterpret_cast<int *>(gp)[u] = base;
@@ -280,6 +347,14 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 				if (k < maxlen)
 					val[vb + k * C + r] = v;                   // steps past the longest row exist in the index groups only
 				const unsigned d = (unsigned) (c - base);
+				if (md == 5)
+				{
+					// an exception lane's correction of this step: one signed byte at 4 * (its rank among the exception lanes) + u
+					// (the idx array starts out zeroed: padding steps and the tail of the 16-byte-padded group stay 0)
+					if (((exmask >> r) & 1ull) && k < maxlen)
+						reinterpret_cast<signed char *>(gp + 16)[4 * __builtin_popcountll(exmask & ((1ull << r) - 1ull)) + u] = (signed char) (c - (base + off5[r]));
+					continue;
+				}
 				if (md == 0 || md == 3)
 					continue;                                  // column = base + lane offset, nothing stored per lane and step
 				if (md == 1)

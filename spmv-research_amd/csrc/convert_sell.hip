@@ -63,6 +63,51 @@ group_bytes(int md)
 	return (md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
 }
 
+// Mode 5 (kernels_sell.hip): every lane of a slice of equally long rows gets the offset off = its first column - the reference lane's
+// first column; a lane is REGULAR when column_k = column_k[reference] + off at every step, an EXCEPTION when the difference fits a
+// signed byte at every step, HARD otherwise. The reference lanes 0..3 are tried in turn; the first one with at least 48 regular lanes,
+// at least one exception and no hard lane is taken. Returns the 64-bit mask of the exception lanes (every lane the same value) and,
+// through `hard`, whether some lane needs more than 8 bits.
+constexpr int SELL5_MIN_REGULAR = 48;
+
+__device__ __forceinline__ unsigned long long
+sell5_exceptions(const int * __restrict__ ci, int start, int maxlen, int r, bool & hard)
+{
+	int regular = 1, fits = 1, off = 0;
+	for (int k = 0; k < maxlen; k++)
+	{
+		const int c = ci[start + k];
+		const int rel = c - __shfl(c, r, WAVE);
+		if (k == 0)
+			off = rel;
+		else
+		{
+			regular = regular && rel == off;
+			fits = fits && rel - off >= -128 && rel - off <= 127;
+		}
+	}
+	hard = __ballot(!fits) != 0ull;
+	return ~__ballot(regular);
+}
+
+__device__ __forceinline__ void
+sell5_reference(const int * __restrict__ ci, int start, int maxlen, int lane, int & ref, int & nex)
+{
+	(void) lane;
+	ref = -1;
+	nex = 0;
+	for (int r = 0; r < 4 && ref < 0; r++)
+	{
+		bool hard;
+		const int e = __popcll(sell5_exceptions(ci, start, maxlen, r, hard));
+		if (WAVE - e >= SELL5_MIN_REGULAR && e > 0 && !hard)
+		{
+			ref = r;
+			nex = e;
+		}
+	}
+}
+
 // pass 1: one wave per slice -> mode, number of value slots, number of index bytes
 __global__ __launch_bounds__(CV_BLOCK) void
 slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, const int * __restrict__ row_of_sorted, long m, long n,
@@ -111,13 +156,20 @@ slice_shape_kernel(const int * __restrict__ rp, const int * __restrict__ ci, con
 	}
 	if (!rowoff)
 		affine = (uniform && maxlen == 0) ? 1 : 0;
+	// lane offsets with exceptions (mode 5): the slice is not of one pattern, but at least 48 of its 64 rows are — against one of the
+	// first four lanes as the reference (a reference that is itself out of line agrees with nobody)
+	int ref = -1, nex = 0;
+	if (uniform && maxlen > 0 && !rowoff && !(modes_off & 4))
+		sell5_reference(ci, start, maxlen, lane, ref, nex);
 	if (lane == 0)
 	{
-		// modes_off (sensitivity experiments, sell_modes_off()): bit 0 forbids the affine mode, bit 1 the per-slice lane offsets
-		const int md = (affine && !(modes_off & 1)) ? 0 : (rowoff && !(modes_off & 2)) ? 3 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
-		mode[sl] = (unsigned char) md;
+		// modes_off (sensitivity experiments, sell_modes_off()): bit 0 forbids the affine mode, bit 1 the per-slice lane offsets,
+		// bit 2 the lane offsets with exceptions
+		const int md = (affine && !(modes_off & 1)) ? 0 : (rowoff && !(modes_off & 2)) ? 3 : ref >= 0 ? 5 : maxdelta < 256 ? 1 : maxdelta < 65536 ? 2 : 4;
+		mode[sl] = (unsigned char) (md == 5 ? (5 | ref << 3) : md);
 		val_count[sl] = (int64_t) maxlen * WAVE;             // values: exact width; index groups: rounded up to 4 steps
-		idx_count[sl] = (int64_t) (md == 3 ? 4 * WAVE : 0) + (int64_t) (width / 4) * group_bytes(md);
+		idx_count[sl] = md == 5 ? (int64_t) (4 * WAVE + 16) + (int64_t) (width / 4) * (16 + (nex + 3) / 4 * 16)
+		                        : (int64_t) (md == 3 ? 4 * WAVE : 0) + (int64_t) (width / 4) * group_bytes(md);
 	}
 }
 
@@ -145,7 +197,7 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 	const int64_t vb = val_ptr[sl];
 	const int maxlen = (int) ((val_ptr[sl + 1] - vb) / WAVE);
 	const int width = (maxlen + 3) / 4 * 4;
-	const int md = mode[sl];
+	const int md = mode[sl] & 7, ref = mode[sl] >> 3;
 	unsigned char * ib = idx + idx_ptr[sl];
 	if (lane == 0)
 	{
@@ -160,8 +212,30 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 		start = rp[o];
 		len = rp[o + 1] - start;
 	}
-	const long gbytes = group_bytes(md);
+	long gbytes = group_bytes(md);
 	int pad_base = 0;
+	bool ex = false;
+	int ex_rank = 0, off5 = 0, nex5 = 0;
+	if (md == 5)
+	{
+		// header: the 64 lane offsets relative to the reference lane's first column, the exception mask, padding
+		bool hard;
+		const unsigned long long mask = sell5_exceptions(ci, start, maxlen, ref, hard);
+		ex = (mask >> lane) & 1ull;
+		ex_rank = __popcll(mask & ((1ull << lane) - 1ull));
+		const int c_first = ci[start];
+		off5 = c_first - __shfl(c_first, ref, WAVE);
+		reinterpret_cast<int *>(ib)[lane] = off5;
+		pad_base = -wave_min_i(off5);                      // all-padding steps: base + off must stay a valid column
+		if (lane == 0)
+		{
+			reinterpret_cast<unsigned long long *>(ib + 4 * WAVE)[0] = mask;
+			reinterpret_cast<unsigned long long *>(ib + 4 * WAVE)[1] = 0ull;
+		}
+		ib += 4 * WAVE + 16;
+		nex5 = __popcll(mask);
+		gbytes = 16 + (nex5 + 3) / 4 * 16;
+	}
 	if (md == 3)
 	{
 		// header: the 64 lane offsets relative to lane 0's column, then the groups of 4 bases
@@ -175,6 +249,7 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 	{
 		unsigned char * gp = ib + g * gbytes;
 		unsigned d[4];
+		int cc[4];
 		#pragma unroll
 		for (int u = 0; u < 4; u++)
 		{
@@ -186,8 +261,11 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 				base = 0;                              // a step that is padding for every lane
 			if (md == 3)                               // base + off[lane]: lane 0's column on a real step
 				base = ok ? __shfl(c, 0, WAVE) : pad_base;
+			if (md == 5)                               // ... the reference lane's (rows of a mode-5 slice are equally long: ok is uniform)
+				base = ok ? __shfl(c, ref, WAVE) : pad_base;
 			if (!ok)
-				c = base;                              // padding: value 0 times a column some lane really uses
+				c = md == 5 ? base + off5 : base;      // padding: value 0 times a column some lane really uses (mode 5: the pattern's, correction 0)
+			cc[u] = md == 5 ? c - (base + off5) : 0;   // mode 5: the correction of this step (0 for a regular lane)
 			if (k < maxlen)                            // steps past the slice's longest row exist in the index groups only
 				val[vb + (long) k * WAVE + lane] = ok ? (T) va[start + k] : (T) 0;
 			if (md != 4)
@@ -198,6 +276,14 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 			}
 			else
 				reinterpret_cast<int *>(gp)[u * WAVE + lane] = c;
+		}
+		if (md == 5)
+		{
+			// the exception lanes' four corrections of the group, one signed byte each; the tail of the 16-byte-padded group is zeroed
+			if (ex)
+				reinterpret_cast<unsigned *>(gp + 16)[ex_rank] = ((unsigned) cc[0] & 255u) | ((unsigned) cc[1] & 255u) << 8 | ((unsigned) cc[2] & 255u) << 16 | ((unsigned) cc[3] & 255u) << 24;
+			if (lane >= nex5 && lane < (int) ((gbytes - 16) / 4))             // dword slots of the group behind the last exception's
+				reinterpret_cast<unsigned *>(gp + 16)[lane] = 0u;
 		}
 		if (md == 1)
 			reinterpret_cast<unsigned *>(gp + 16)[lane] = d[0] | d[1] << 8 | d[2] << 16 | d[3] << 24;
@@ -304,7 +390,7 @@ sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma,
 			HIP_TRY(hipMemcpy(mode_host.data(), mode, (size_t) num_slices, hipMemcpyDeviceToHost));
 		mode_counts[0] = mode_counts[1] = mode_counts[2] = mode_counts[3] = 0;
 		for (long sl = 0; sl < num_slices; sl++)
-			mode_counts[mode_host[sl] == 0 ? 3 : mode_host[sl] == 1 ? 0 : mode_host[sl] == 2 ? 1 : 2]++;
+			mode_counts[((mode_host[sl] & 7) == 0 || (mode_host[sl] & 7) == 3 || (mode_host[sl] & 7) == 5) ? 3 : (mode_host[sl] & 7) == 1 ? 0 : (mode_host[sl] & 7) == 2 ? 1 : 2]++;
 	}
 
 	// 4. fill

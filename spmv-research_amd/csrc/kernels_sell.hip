@@ -248,6 +248,25 @@ sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * 
 	}
 }
 
+// hipcc sinks a load whose result is only used in the NEXT trip of a loop (through `a = na`) down to that use — the loads are
+// invariant, so it may — and the hand-written prefetch becomes a dependent load in front of the gathers again. Passing the prefetched
+// registers through an empty asm statement at the END of the trip pins them to the trip they were issued in: the wait for them lands
+// behind this trip's gathers and FMAs, where it costs nothing.
+__device__ __forceinline__ void
+sell_pin(unsigned & v)
+{
+	asm volatile("" : "+v"(v));
+}
+__device__ __forceinline__ void
+sell_pin(sell_uint2 & v, bool both)
+{
+	unsigned a = v.x, b = both ? v.y : 0u;
+	asm volatile("" : "+v"(a), "+v"(b));
+	v.x = a;
+	if (both)
+		v.y = b;
+}
+
 // Modes 1 and 2 put a dependent load in front of every gather (deltas -> column -> x): their index words are fetched one pair of
 // groups AHEAD, so that a trip costs one exposed round trip (the gathers) like the index-free modes, not two.
 template <int MODE>
@@ -324,6 +343,8 @@ sell_delta_piped(const unsigned char * __restrict__ ip, const T * __restrict__ v
 			s = fma_t<T>(b2, z2, s);
 			s = fma_t<T>(b3, z3, s);
 		}
+		sell_pin(na.d, MODE == 2);
+		sell_pin(nb.d, MODE == 2);
 		a = na;
 		b = nb;
 	}
@@ -373,7 +394,121 @@ sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ v
 	return s;
 }
 
-// desc[2*s] = first value element of slice s, desc[2*s+1] = byte offset of its index block | mode (0, 1, 2, 3 or 4) in the low bits
+// MODE 5: lane offsets WITH EXCEPTIONS. Modes 0 and 3 need all 64 rows of a slice to follow one pattern; one row out of line (a
+// boundary row of a stencil, a perturbed row) used to send the whole slice back to 8/16-bit deltas per lane and step. Here EVERY lane
+// has an offset (its first column minus the reference lane's), the rows that fit (at least 48 of 64) have column = base_k + off_lane
+// at every step, and the E <= 16 others add a signed 8-bit correction per step:
+//     slice header: [64 x int32 lane offsets][u64 exception mask][8 bytes of padding]                       = 272 bytes
+//     group of 4 steps: [4 x int32 base][E x (4 x int8 corrections of exception lane number j)], padded to 16 = 32 .. 80 bytes
+// An exception lane loads its four corrections as ONE dword at gp + 16 + 4 * (its rank among the exception lanes); the other lanes
+// load the first exception's (one address for all of them) and drop it. (A first version stored the exception lanes' columns as
+// 4 x int32 and loaded them with a dwordx4 per lane: 1 447 us on the 5 %-jittered nlpkkt240 twin against 1 425 us for plain 8/16-bit
+// deltas although it moves 7 % fewer bytes — the wide load of all 64 lanes cost more than the bytes saved.) That load sits in front
+// of the lane's gathers, so it is fetched one pair of groups ahead like the delta words of modes 1 / 2. Same FMAs in the same order
+// as every other mode: bit-identical results. A slice with a row that needs more than 8 bits falls back to modes 1 / 2 / 4.
+struct SellDeltaIdx5 {
+	sell_int4 base;                                // wave-uniform
+	unsigned d;                                    // 4 x int8, exception lanes only
+};
+
+// `rank` is 0 for the lanes that are no exception: they load the first exception's corrections (one address for all of them) and drop
+// them. No branch around the load: with one the compiler cannot count what is outstanding and waits for everything at every trip.
+template <bool NT>
+__device__ __forceinline__ void
+sell_delta_load_idx5(SellDeltaIdx5 & q, const unsigned char * __restrict__ gp /* uniform */, int rank)
+{
+	q.base = *reinterpret_cast<const sell_int4 *>(gp);
+	q.d = ld_stream<NT>(reinterpret_cast<const unsigned *>(gp + 16) + rank);
+}
+
+__device__ __forceinline__ void
+sell_delta_cols5(const SellDeltaIdx5 & q, bool ex, int off, int (&c)[4])
+{
+	const int d = ex ? (int) q.d : 0;
+	c[0] = q.base.x + off + ((d << 24) >> 24);
+	c[1] = q.base.y + off + ((d << 16) >> 24);
+	c[2] = q.base.z + off + ((d << 8) >> 24);
+	c[3] = q.base.w + off + (d >> 24);
+}
+
+template <typename T, bool NT>
+__device__ __forceinline__ T
+sell_delta_slice5(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int width, int lane, const T * __restrict__ x,
+		int g0 = 0, int gs = 1)
+{
+	const int off = ld_stream<NT>(reinterpret_cast<const int *>(ip) + lane);
+	const unsigned long long mask = *reinterpret_cast<const unsigned long long *>(ip + 4 * WAVE);          // uniform: a scalar load
+	ip += 4 * WAVE + 16;
+	const int E = __popcll(mask);
+	const bool ex = (mask >> lane) & 1ull;
+	const int rank = ex ? __popcll(mask & ((1ull << lane) - 1ull)) : 0;
+	const size_t GB = 16 + ((size_t) E + 3) / 4 * 16;
+	const int groups = (width + 3) / 4;
+	const int rem = width - 4 * (groups - 1);
+	const int last = groups - 1;
+	const int full = rem == 4 ? groups : last;
+	const int n = full > g0 ? (full - g0 + gs - 1) / gs : 0;     // full groups this wave takes: g0, g0 + gs, ...
+	T s = 0;
+	SellDeltaIdx5 a, b, na, nb;
+	if (n > 0)
+	{
+		auto gidx = [&](int k) { return g0 + (k < n ? k : n - 1) * gs; };       // past the end: the last group again (loaded, not used)
+		sell_delta_load_idx5<NT>(a, ip + (size_t) gidx(0) * GB, rank);
+		sell_delta_load_idx5<NT>(b, ip + (size_t) gidx(1) * GB, rank);
+		for (int k = 0; k < n; k += 2)
+		{
+			const int ga = gidx(k), gb = gidx(k + 1);
+			sell_delta_load_idx5<NT>(na, ip + (size_t) gidx(k + 2) * GB, rank);
+			sell_delta_load_idx5<NT>(nb, ip + (size_t) gidx(k + 3) * GB, rank);
+			const T * va = vp + (size_t) ga * 4 * WAVE;
+			const T * vb = vp + (size_t) gb * 4 * WAVE;
+			const T a0 = ld_stream<NT>(va), a1 = ld_stream<NT>(va + WAVE), a2 = ld_stream<NT>(va + 2 * WAVE), a3 = ld_stream<NT>(va + 3 * WAVE);
+			const T b0 = ld_stream<NT>(vb), b1 = ld_stream<NT>(vb + WAVE), b2 = ld_stream<NT>(vb + 2 * WAVE), b3 = ld_stream<NT>(vb + 3 * WAVE);
+			int ca[4], cb[4];
+			sell_delta_cols5(a, ex, off, ca);
+			sell_delta_cols5(b, ex, off, cb);
+			const T x0 = x[ca[0]], x1 = x[ca[1]], x2 = x[ca[2]], x3 = x[ca[3]];
+			const T z0 = x[cb[0]], z1 = x[cb[1]], z2 = x[cb[2]], z3 = x[cb[3]];
+			s = fma_t<T>(a0, x0, s);
+			s = fma_t<T>(a1, x1, s);
+			s = fma_t<T>(a2, x2, s);
+			s = fma_t<T>(a3, x3, s);
+			if (k + 1 < n)                               // wave-uniform: an odd count ends on a single group
+			{
+				s = fma_t<T>(b0, z0, s);
+				s = fma_t<T>(b1, z1, s);
+				s = fma_t<T>(b2, z2, s);
+				s = fma_t<T>(b3, z3, s);
+			}
+			sell_pin(na.d);
+			sell_pin(nb.d);
+			a = na;
+			b = nb;
+		}
+	}
+	// the last group of a slice whose width is not a multiple of 4 (the value array holds only its `rem` real steps); with several
+	// waves per slice it belongs to the wave whose sequence g0, g0 + gs, ... reaches it
+	if (rem != 4 && last >= g0 && (last - g0) % gs == 0)
+	{
+		SellDeltaIdx5 q;
+		sell_delta_load_idx5<NT>(q, ip + (size_t) last * GB, rank);
+		int c[4];
+		sell_delta_cols5(q, ex, off, c);
+		const T * vl = vp + (size_t) last * 4 * WAVE;
+		const T v0 = ld_stream<NT>(vl);
+		const T v1 = rem > 1 ? ld_stream<NT>(vl + WAVE) : T(0);
+		const T v2 = rem > 2 ? ld_stream<NT>(vl + 2 * WAVE) : T(0);
+		const T x0 = x[c[0]];
+		const T x1 = rem > 1 ? x[c[1]] : T(0);
+		const T x2 = rem > 2 ? x[c[2]] : T(0);
+		s = fma_t<T>(v0, x0, s);
+		if (rem > 1) s = fma_t<T>(v1, x1, s);
+		if (rem > 2) s = fma_t<T>(v2, x2, s);
+	}
+	return s;
+}
+
+// desc[2*s] = first value element of slice s, desc[2*s+1] = byte offset of its index block | mode (0 .. 5) in the low bits
 template <typename T, bool NT>
 __global__ __launch_bounds__(SELL_BLOCK) void
 sell_delta_kernel(const int64_t * __restrict__ desc, const unsigned char * __restrict__ idx, const T * __restrict__ val,
@@ -403,6 +538,8 @@ sell_delta_kernel(const int64_t * __restrict__ desc, const unsigned char * __res
 		s = sell_delta_slice<T, 2, NT>(ip, vp, groups, lane, x);
 	else if (mode == 3)
 		s = sell_delta_slice<T, 3, NT>(ip, vp, groups, lane, x);
+	else if (mode == 5)
+		s = sell_delta_slice5<T, NT>(ip, vp, groups, lane, x);
 	else
 		s = sell_delta_slice<T, 4, NT>(ip, vp, groups, lane, x);
 	const long sorted_row = (long) slice * WAVE + lane;
@@ -449,6 +586,8 @@ sell_delta_split_kernel(const int64_t * __restrict__ desc, const unsigned char *
 			s = sell_delta_slice<T, 2, NT>(ip, vp, groups, lane, x, w, S);
 		else if (mode == 3)
 			s = sell_delta_slice<T, 3, NT>(ip, vp, groups, lane, x, w, S);
+		else if (mode == 5)
+			s = sell_delta_slice5<T, NT>(ip, vp, groups, lane, x, w, S);
 		else
 			s = sell_delta_slice<T, 4, NT>(ip, vp, groups, lane, x, w, S);
 	}

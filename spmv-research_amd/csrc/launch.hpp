@@ -74,12 +74,13 @@ int launch_sell_window(bool f32, int waves_per_slice, int slices_per_group, cons
 		hipStream_t stream, long * grid_out);
 
 // Sensitivity experiments on the delta layout's index-free modes: SPMV_MI355X_SELL_MODES_OFF, bit 0 = no affine slices (mode 0),
-// bit 1 = no per-slice lane offsets (mode 3); such slices then store 8- / 16-bit deltas per lane. Read at every create().
+// bit 1 = no per-slice lane offsets (mode 3), bit 2 = no lane offsets with exceptions (mode 5); such slices then store 8- / 16-bit
+// deltas per lane. Read at every create().
 inline int
 sell_modes_off()
 {
 	const char * e = getenv("SPMV_MI355X_SELL_MODES_OFF");
-	return e ? atoi(e) & 3 : 0;
+	return e ? atoi(e) & 7 : 0;
 }
 
 // CSR -> SELL-64-sigma-delta on the GPU (convert_sell.hip); outputs are device arrays owned by the caller

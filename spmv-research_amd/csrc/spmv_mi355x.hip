@@ -458,9 +458,15 @@ spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma
 				const int md = (int) (h_desc[2 * sl + 1] & 7);
 				const unsigned char * ib = h_idx.data() + (h_desc[2 * sl + 1] & ~(int64_t) 15);
 				const int * offs = reinterpret_cast<const int *>(ib);
+				unsigned long long exmask = 0;
 				if (md == 3)
 					ib += 4 * 64;
-				const long gbytes = (md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
+				if (md == 5)
+				{
+					exmask = *reinterpret_cast<const unsigned long long *>(ib + 4 * 64);
+					ib += 4 * 64 + 16;
+				}
+				const long gbytes = md == 5 ? 16 + (__builtin_popcountll(exmask) + 3) / 4 * 16 : (md == 0 || md == 3) ? 16 : md == 1 ? 272 : md == 2 ? 528 : 1024;
 				for (long k = 0; k < width; k++)
 				{
 					const unsigned char * gp = ib + (k / 4) * gbytes;
@@ -472,6 +478,9 @@ spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma
 							c = reinterpret_cast<const int *>(gp)[u] + r;
 						else if (md == 3)
 							c = reinterpret_cast<const int *>(gp)[u] + offs[r];
+						else if (md == 5)
+							c = reinterpret_cast<const int *>(gp)[u] + offs[r] +
+							    (((exmask >> r) & 1ull) ? (int) reinterpret_cast<const signed char *>(gp + 16)[4 * __builtin_popcountll(exmask & ((1ull << r) - 1ull)) + u] : 0);
 						else if (md == 1)
 							c = reinterpret_cast<const int *>(gp)[u] + gp[16 + r * 4 + u];
 						else if (md == 2)

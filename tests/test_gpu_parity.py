@@ -390,6 +390,53 @@ def test_device_conversion_equals_host_conversion(eng, oracle, name):
             D.close()
 
 
+@pytest.mark.parametrize("frac,span", [(0.05, 3), (0.25, 64), (0.6, 3)])
+def test_lane_offsets_with_exceptions(eng, oracle, monkeypatch, frac, span):
+    """Mode 5 of the delta layout (kernels_sell.hip): a slice whose rows follow one stencil pattern except for a few keeps its
+    index-free lane offsets, the rows out of line carry explicit columns. A KKT twin with a fraction of its rows perturbed: host and
+    GPU builders give the same bytes, the layout decodes back to the CSR columns, y is bit-identical to the sequential CPU kernel
+    (one lane per row, same FMAs), with one and with several waves per slice — and the mode is really taken (fewer index bytes
+    than with it switched off) as long as at most 16 of a slice's 64 rows are out of line."""
+    import spmv_host as H
+    A = H.jitter_columns(H.gen_kkt(20), frac, span)
+    rp, ci, a, m, n = A["row_ptr"], A["col_idx"], A["values"], A["m"], A["n"]
+    x = np.random.default_rng(17).uniform(-1, 1, n)
+    for dtype in (np.float64, np.float32):
+        y_ref = oracle.csr_spmv(rp, ci, a, x, dtype, num_threads=1)
+        Hm = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=16384, sell_split=1, convert_on=2)
+        Dm = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=16384, sell_split=1, convert_on=1)
+        lh, ld = Hm.sell_layout(), Dm.sell_layout()
+        assert Dm.mem_footprint == Hm.mem_footprint
+        for k in ("row_of_sorted", "slice_ptr", "col", "val"):
+            np.testing.assert_array_equal(ld[k], lh[k], err_msg=k)
+        # the decoded layout holds the CSR's columns: slice s, step k, lane r = entry k of sorted row 64 s + r
+        ros, sp, col = ld["row_of_sorted"], ld["slice_ptr"], ld["col"]
+        for sl in (0, len(sp) // 2, len(sp) - 2):
+            width = (sp[sl + 1] - sp[sl]) // 64
+            for r in (0, 1, 17, 63):
+                if sl * 64 + r < m:
+                    row = ros[sl * 64 + r]
+                    ln = rp[row + 1] - rp[row]
+                    np.testing.assert_array_equal(col[sp[sl] + np.arange(min(ln, width)) * 64 + r], ci[rp[row]:rp[row] + min(ln, width)])
+        np.testing.assert_array_equal(Dm.spmv(x), y_ref)
+        np.testing.assert_array_equal(Hm.spmv(x), y_ref)
+        for S in (2, 4):
+            W = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=16384, sell_split=S)
+            err = np.abs(W.spmv(x).astype(np.float64) - y_ref.astype(np.float64))
+            assert np.all(err <= (1e-12 if dtype == np.float64 else 1e-5) * oracle.csr_spmv(rp, ci, np.abs(a), np.abs(x)))
+            W.close()
+        with_mode = Dm.mem_footprint
+        Hm.close()
+        Dm.close()
+        monkeypatch.setenv("SPMV_MI355X_SELL_MODES_OFF", "4")
+        Off = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=16384, sell_split=1)
+        np.testing.assert_array_equal(Off.spmv(x), y_ref)
+        if frac <= 0.25:
+            assert with_mode < Off.mem_footprint, (with_mode, Off.mem_footprint)
+        Off.close()
+        monkeypatch.delenv("SPMV_MI355X_SELL_MODES_OFF")
+
+
 @pytest.mark.parametrize("C_rows,sigma", [(256, 16384), (64, 16384), (256, 512), (64, 64)])
 def test_sell_layout_equals_the_bsc_library_layout(eng, oracle, C_rows, sigma):
     """Row a7: the engine's plain SELL-C-sigma layout against the oracle's restatement of the BSC library's
