@@ -70,6 +70,8 @@ ALSO_KERNELS = {"soc-LiveJournal1": [("csr_merge", {"col_blocks": -1})], "scircu
                 "cant": [("csr_stream", {})]}            # cant: the CSR-storage kernel with the x window in LDS (16-bit columns), beside the named csr_vector
 # configs 1-4: timed after the headline at N = 1
 SMALL_CONFIGS = ("cant", "scircuit", "pwtk", "soc-LiveJournal1")
+# the two banded FEM twins also get a symmetric-storage leg
+SYMMETRIC_CONFIGS = ("cant", "pwtk")
 
 
 def parse(argv=None):
@@ -417,6 +419,8 @@ def run_small_configs(E, torch, H, args):
             rec.update({"named_cold_ms": round(named["cold_ms"], 6), "named_cold_frac": round(B / (named["cold_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                         "best_cold_ms": round(best["cold_ms"], 6), "cold_frac": round(B / (best["cold_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                         "cold": "isolated launches, a 1 GiB buffer overwritten before each (bench_spmv.cpp:331-348 CLEAR_CACHES); median of 15"})
+        if w in SYMMETRIC_CONFIGS:
+            rec["symmetric_storage"] = symmetric_storage_leg(E, torch, A, dts, steps, warm)
         if not args.no_cpu_baseline:
             # the reference's CPU CSR kernel on the same matrix (whole matrix where it has <= 64 M non-zeros: config 1 IS this on cant)
             saved = args.cpu_baseline_seconds
@@ -425,6 +429,52 @@ def run_small_configs(E, torch, H, args):
             args.cpu_baseline_seconds = saved
         out.append(rec)
         del A, named, best
+    return out
+
+
+def symmetric_storage_leg(E, torch, A, dts, steps, warm):
+    """Row f4 (KEEP_SYMMETRY builds, csr_sym.cpp): the LOWER triangle of the twin as the stored triangle of a symmetric matrix
+    (T + T^t - diag T: the twin mirrored, not the twin itself), multiplied by the symmetric-storage kernel WITHOUT expanding it, beside
+    the same symmetric matrix expanded and run through the general SELL path. Fractions are on the EXPANDED matrix's algorithmic bytes."""
+    import scipy.sparse as sp
+    m = A["m"]
+    M = sp.csr_matrix((A["values"], A["col_idx"], A["row_ptr"]), shape=(m, m))
+    T = sp.tril(M).tocsr()
+    T.sort_indices()
+    Ex = (T + sp.tril(M, -1).T).tocsr()
+    Ex.sort_indices()
+    tri = dict(m=m, n=m, nnz=int(T.nnz), row_ptr=T.indptr.astype(np.int32), col_idx=T.indices.astype(np.int32), values=T.data.astype(np.float64))
+    full = dict(m=m, n=m, nnz=int(Ex.nnz), row_ptr=Ex.indptr.astype(np.int32), col_idx=Ex.indices.astype(np.int32), values=Ex.data.astype(np.float64))
+    B = algorithmic_bytes(m, m, int(Ex.nnz), 8 if dts == "f64" else 4)
+    # the sampled-row check of time_handle multiplies the arrays it is given: hand it the expanded matrix, the handle the triangle
+    np_dtype = np.float64 if dts == "f64" else np.float32
+    x_host = np.random.default_rng(14).uniform(-1.0, 1.0, m).astype(np_dtype)
+    S = E.Matrix(tri["row_ptr"], tri["col_idx"], tri["values"], m, m, "sell_c_sigma", np_dtype, symmetric_input=1, sell_window=1, placement=1)
+    S.upload_x(x_host)
+    xp, yp = S.x_device(), S.y_device()
+    sp_ = torch.cuda.current_stream().cuda_stream
+    t0 = time.time()
+    while time.time() - t0 < max(warm, 0.05):
+        S.time_device(xp, yp, 50, sp_)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k_ms = S.time_device(xp, yp, steps, sp_)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / steps * 1e3
+    yh = S.download_y().astype(np.float64)
+    err, _ = sampled_row_check(yh, full["row_ptr"], full["col_idx"], full["values"], x_host, np_dtype)
+    tol = 1e-12 if dts == "f64" else 1e-5
+    if not (err <= tol):
+        raise SystemExit(f"bench sanity check failed for {S.format_name}: {err}")
+    out = {"what": "lower triangle of the twin stored, y = (T + T^t - diag T) x without expanding it (csr_sym.cpp:191-267)",
+           "format": S.format_name, "kernel": S.kernel_info()["name"], "stored_nnz": int(T.nnz), "expanded_nnz": int(Ex.nnz),
+           "mem_footprint": S.mem_footprint, "ms": round(wall_ms, 6), "kernel_ms": round(k_ms, 6),
+           "frac_on_expanded_bytes": round(B / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "check_max_err_over_abs_row": err,
+           "traffic": None}
+    S.close()
+    g = time_handle(E, torch, full, "sell_c_sigma", dts, {}, steps, 20, x_host=x_host, min_warm_seconds=warm)
+    out["expanded"] = {"format": g["format_name"], "ms": round(g["wall_ms"], 6), "mem_footprint": g["mem_footprint"],
+                       "frac": round(B / (g["wall_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     return out
 
 

@@ -82,7 +82,11 @@ typedef struct {
 	                           2 = host (OpenMP; kept as the checker — both produce the same bytes)                    */
 	int  symmetric_input;   /* 1 = the CSR arrays hold ONE triangle of a symmetric matrix (KEEP_SYMMETRY builds of the harness:
 	                           csr_to_format(..., symmetric = 1, symmetry_expanded = 0), csr_sym.cpp:118-123); the product is
-	                           y = (T + T^t - diag T) x. Expanded at create(); rows()/nnz() then report the expanded matrix */
+	                           y = (T + T^t - diag T) x; rows()/nnz() report the expanded matrix. SELL_C_SIGMA on a banded matrix
+	                           (every slice group's window of rows + columns fits LDS: (w + 1) * (sizeof(V) + 8) <= 152 KiB) keeps the
+	                           triangle and multiplies without expanding it — half the matrix stream, the mirrored additions as LDS
+	                           atomics (csrc/kernels_sell_window.hip) — on its own when the expanded stream exceeds the 256 MiB
+	                           Infinity Cache, always with sell_window = 1. Everything else expands the triangle at create().        */
 	int  rows_per_group;    /* CSR_VECTOR: consecutive rows a lane group keeps in flight together (1, 2 or 4; 2 and 4 need
 	                           lanes_per_row >= 8); 0 = auto                                                        */
 	int  col_blocks;        /* COO: 0 = row-sorted COO (the reference's layout); -1 = column-blocked layout for graph matrices: the rows are

@@ -394,7 +394,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 // sigma = 64*NS). Returns 0 = built, 1 = error, 2 = not applicable (a group's window is wider than 65 536 columns or than
 // the LDS budget): the caller falls back to the delta layout.
 static int
-build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va, int NS, int S, long lds_budget_bytes)
+build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va, int NS, int S, long lds_budget_bytes, bool sym = false)
 {
 	const long m = A->m;
 	constexpr int C = 64;
@@ -415,10 +415,17 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 			lo = std::min(lo, ci[j]);
 			hi = std::max(hi, ci[j]);
 		}
+		if (sym)
+		{
+			// symmetric storage: the window also covers the group's own rows (x[i] of every row is read, y[i] written through it)
+			lo = std::min<long>(lo, r0);
+			hi = std::max<long>(hi, r1 - 1);
+		}
 		if (hi < 0)
 			lo = 0;
 		const long w = hi < 0 ? 1 : (long) hi - lo + 1;
-		if (w > 65535 || (w + 1) * (long) A->vbytes > lds_budget_bytes)          // one more LDS slot behind the window holds a zero
+		// one more LDS slot behind the window holds a zero; symmetric storage keeps an fp64 y window beside the x window
+		if (w > 65534 || (w + 1) * (long) (A->vbytes + (sym ? 8 : 0)) > lds_budget_bytes)
 			too_wide++;
 		grp[(size_t) 4 * g] = lo;
 		grp[(size_t) 4 * g + 1] = (int) std::min<long>(w, 0x7fffffffL);
@@ -474,7 +481,8 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 			}
 			// padding: value 0 times a window entry the row already reads (its last column); an EMPTY row reads the zero the kernel
 			// keeps behind the window (its y must be 0 whatever x holds: 0 * Inf from a neighbour's column would make it NaN)
-			const unsigned short pad = len > 0 ? (unsigned short) (ci[js + len - 1] - lo) : (unsigned short) gw;
+			// (symmetric storage: every padding entry points at the spare slot — its mirrored addition must not land in a real row)
+			const unsigned short pad = (len > 0 && !sym) ? (unsigned short) (ci[js + len - 1] - lo) : (unsigned short) gw;
 			for (long k = 0; k < width; k++)
 			{
 				val[(size_t) (vb + k * C + r)] = k < len ? va[js + k] : 0.0;
@@ -503,6 +511,39 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 	    upload_ints(row_of_sorted.data(), (size_t) m, &A->d_row_of_sorted))
 		return 1;
 	A->mem_footprint = (double) (num_slices + 1) * 16 + (double) num_groups * 16 + (double) nnz_ext * A->vbytes + (double) idx_count * 2 + (double) m * 4;
+	return 0;
+}
+
+// symmetric storage in (opts.symmetric_input), SELL-C-sigma asked for: the stored triangle in the LDS-window layout, multiplied without
+// expanding it (sell_window_sym_kernel). A->m / n / nnz describe the EXPANDED matrix (what rows() / nnz() report), rp / ci / va the
+// triangle. Returns 0 = built, 1 = error, 2 = not applicable (some slice group's window of rows + columns does not fit LDS or 16 bits):
+// the caller then expands the triangle and takes the general path.
+int
+build_sell_symmetric(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * rp, const int * ci, const double * va)
+{
+	const long lm = A->m;
+	const long slices = (lm + 63) / 64;
+	const char * pf = A->f32 ? "f" : "d";
+	int S = o.sell_split ? o.sell_split : (slices >= 8192 ? 1 : slices >= 2048 ? 2 : 4);
+	int NS = o.sell_group ? o.sell_group : 16 / S;
+	if ((S != 1 && S != 2 && S != 4) || NS < 1 || NS * S > 16 || (NS & (NS - 1)))
+		return 2;
+	A->sell_c = 64;
+	A->sell_delta = false;
+	const int took = build_sell_window(A, rp, ci, va, NS, S, 152 * 1024, true);
+	if (took)
+		return took;
+	A->sell_window = true;
+	A->sell_sym = true;
+	A->sell_sigma = 64L * NS;
+	if (o.nontemporal == 0)
+		A->cfg.nt = (double) A->sell_nnz_ext * (A->vbytes + 2) > 32.0 * 1024 * 1024 ? 1 : 0;
+	if (S > 1)
+		snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELLWS_64_%d_w%d_%s", 64 * NS, S, pf);
+	else
+		snprintf(A->format_name, sizeof(A->format_name), "MI355X_SELLWS_64_%d_%s", 64 * NS, pf);
+	snprintf(A->kernel_name, sizeof(A->kernel_name), "sell_window_sym_kernel");
+	A->kernel_block = 64 * NS * S;
 	return 0;
 }
 

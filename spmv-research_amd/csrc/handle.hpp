@@ -65,6 +65,7 @@ struct spmv_mi355x_matrix {
 	unsigned char * d_sell_idx = nullptr;
 	long sell_idx_bytes = 0;
 	bool sell_window = false;              // x window of a slice group in LDS, 16-bit window-relative indices (kernels_sell_window.hip)
+	bool sell_sym = false;                 // the window layout holds ONE TRIANGLE of a symmetric matrix (sell_window_sym_kernel)
 	int * d_sellw_grp = nullptr;           // [groups][4]: window start, width, first slice, slices
 	int sellw_groups = 0, sellw_ns = 0, sellw_lds = 0;
 	long sell_mode_slices[4] = {0, 0, 0, 0};  // slices stored with 8-bit / 16-bit / 32-bit indices / none (affine)
@@ -132,6 +133,7 @@ int prepare_local_csr(const spmv_mi355x_opts & o, long m, long n, long nnz, cons
 // ---- per-format builders (= the reference's csr_to_format constructors): fill the handle from the local CSR
 int build_csr_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * rp, const int * ci, const double * va);   // build_csr.hip
 int build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * rp, const int * ci, const double * va);  // build_sell.hip
+int build_sell_symmetric(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * rp, const int * ci, const double * va);   // build_sell.hip: 0 built, 1 error, 2 not applicable
 int build_coo_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int * rp, const int * ci, const double * va);   // build_coo.hip
 // the column-blocked layout shared by COO (ranges = equal shares of the non-zeros) and merge path (equal shares of rows + non-zeros)
 int build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double * va, int col_blocks, bool merge_balance);

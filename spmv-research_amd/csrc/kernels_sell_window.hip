@@ -201,6 +201,176 @@ sell_window_dispatch(int S, int threads, const int * grp, const int64_t * sdesc,
 	return 1;
 }
 
+// ------------------------------------------------------------------------------------------------ symmetric storage
+// One stored triangle T of a symmetric matrix (KEEP_SYMMETRY builds of the harness: csr_to_format(..., symmetric = 1,
+// symmetry_expanded = 0), csr_sym.cpp:118-123; the product is y = (T + T^t - diag T) x, csr_sym.cpp:191-267, gold in
+// bench_spmv.cpp:135-148) in the SAME layout — slice groups, 16-bit window-relative columns — multiplied WITHOUT expanding it:
+// half the matrix stream. A stored entry (i, j, a) adds a*x[j] to the row's accumulator (a register, as above) and, when j != i,
+// a*x[i] to y[j]. That second, scattered addition is what makes symmetric storage a bad trade on a GPU in general (fp64 atomics on
+// scattered global addresses: 24 G/s, tools/atomic_bench.hip) — but for a BANDED matrix j lies inside the slice group's own column
+// window, which this kernel already keeps in LDS for x: the group keeps a y window beside it (fp64 for both precisions) and the
+// scatter is an LDS atomic (ds_add_f64: 0.44 clocks per entry and CU, profiles/r03_gather_bench2.txt). When the group is done its
+// y window — the group's own rows and the rows above / below them that its entries reach — is added to y in global memory with
+// one coalesced sweep of atomics (contiguous fp64 atomics: 175 G/s), so neighbouring groups' windows may overlap freely. y is
+// cleared first (beta = 0). The window covers the group's rows as well as its columns (the diagonal need not be stored).
+// Padding entries point at the spare slot behind the window (x = 0, a y nobody reads). Sums to the tolerance, not bit-reproducible
+// (atomics) — neither is the reference's csr_sym kernel with more than one thread (compare-and-swap scatter, csr_sym.cpp:204-232).
+template <typename T>
+__device__ __forceinline__ void
+sellw_sym_group(sellw_uint2 d, const T (&v)[4], const T * __restrict__ xs, double * __restrict__ ys, unsigned me, T xi, T & s)
+{
+	const unsigned j0 = d.x & 0xffffu, j1 = d.x >> 16, j2 = d.y & 0xffffu, j3 = d.y >> 16;
+	const T x0 = xs[j0], x1 = xs[j1], x2 = xs[j2], x3 = xs[j3];
+	s = fma_t<T>(v[0], x0, s);
+	s = fma_t<T>(v[1], x1, s);
+	s = fma_t<T>(v[2], x2, s);
+	s = fma_t<T>(v[3], x3, s);
+	// the mirrored entries: nothing for a diagonal entry (j == i) — branch-free, an add of zero
+	unsafeAtomicAdd(&ys[j0], j0 == me ? 0.0 : (double) v[0] * (double) xi);
+	unsafeAtomicAdd(&ys[j1], j1 == me ? 0.0 : (double) v[1] * (double) xi);
+	unsafeAtomicAdd(&ys[j2], j2 == me ? 0.0 : (double) v[2] * (double) xi);
+	unsafeAtomicAdd(&ys[j3], j3 == me ? 0.0 : (double) v[3] * (double) xi);
+}
+
+template <typename T, int S, bool NT>
+__global__ __launch_bounds__(1024) void
+sell_window_sym_kernel(const int * __restrict__ grp, const int64_t * __restrict__ sdesc, const unsigned short * __restrict__ idx,
+		const T * __restrict__ val, const int * __restrict__ row_of_sorted, const T * __restrict__ x, T * __restrict__ y,
+		int m, int ys_off /* bytes from the x window to the y window */, XcdMap map)
+{
+	extern __shared__ __align__(16) unsigned char sellw_smem[];
+	T * xs = reinterpret_cast<T *>(sellw_smem);
+	double * ys = reinterpret_cast<double *>(sellw_smem + ys_off);
+	const unsigned tile = xcd_tile(blockIdx.x, map);
+	if (tile == NO_TILE)
+		return;
+	const int lo = grp[4 * tile], w = grp[4 * tile + 1], slice0 = grp[4 * tile + 2], ns = grp[4 * tile + 3];
+	const int lane = threadIdx.x % WAVE;
+	const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x / WAVE);
+	const int part = wave % S;
+	const bool active = wave / S < ns;
+	const int slice = slice0 + (active ? wave / S : 0);
+	const int64_t v_off = sdesc[2 * slice], i_off = sdesc[2 * slice + 1], v_next = sdesc[2 * slice + 2];
+	const int groups = (int) ((v_next - v_off) / (4 * WAVE));
+	const T * vp = val + v_off + lane;
+	const sellw_uint2 * ip = reinterpret_cast<const sellw_uint2 *>(idx + i_off) + lane;
+	const long sorted_row = (long) slice * WAVE + lane;
+	const bool mine = active && sorted_row < m;
+	const int row = mine ? row_of_sorted[sorted_row] : lo;
+	for (int i = threadIdx.x; i < w; i += blockDim.x)
+	{
+		xs[i] = x[lo + i];
+		ys[i] = 0;
+	}
+	if (threadIdx.x == 0)
+	{
+		xs[w] = 0;                          // what padding entries read ...
+		ys[w] = 0;                          // ... and add into
+	}
+	__syncthreads();
+	const unsigned me = (unsigned) (row - lo);
+	const T xi = mine ? xs[me] : T(0);
+	T s = 0;
+	if (active)
+	{
+		int g = part;
+		for (; g + S < groups; g += 2 * S)
+		{
+			const sellw_uint2 d0 = ld_stream<NT>(ip + (size_t) g * WAVE), d1 = ld_stream<NT>(ip + (size_t) (g + S) * WAVE);
+			T a[4], b[4];
+			#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				a[u] = ld_stream<NT>(vp + (size_t) g * 4 * WAVE + u * WAVE);
+				b[u] = ld_stream<NT>(vp + (size_t) (g + S) * 4 * WAVE + u * WAVE);
+			}
+			sellw_sym_group<T>(d0, a, xs, ys, me, xi, s);
+			sellw_sym_group<T>(d1, b, xs, ys, me, xi, s);
+		}
+		if (g < groups)
+		{
+			const sellw_uint2 d0 = ld_stream<NT>(ip + (size_t) g * WAVE);
+			T a[4];
+			#pragma unroll
+			for (int u = 0; u < 4; u++)
+				a[u] = ld_stream<NT>(vp + (size_t) g * 4 * WAVE + u * WAVE);
+			sellw_sym_group<T>(d0, a, xs, ys, me, xi, s);
+		}
+		if (mine)
+			unsafeAtomicAdd(&ys[me], (double) s);          // the row's own sum (S waves of a slice each add their part)
+	}
+	__syncthreads();
+	// the group's y window goes to global memory: contiguous atomics, zeros skipped (rows the group does not reach)
+	for (int i = threadIdx.x; i < w; i += blockDim.x)
+	{
+		const double v = ys[i];
+		if (v != 0.0)
+			unsafeAtomicAdd(&y[lo + i], (T) v);
+	}
+}
+
+template <typename T, int S>
+static int
+sell_window_sym_launch_s(int threads, const int * grp, const int64_t * sdesc, const unsigned short * idx, const void * val, const int * row_of_sorted,
+		const void * x, void * y, int m, int lds_window_bytes, const LaunchCfg & cfg, hipStream_t stream, long * grid_out)
+{
+	const unsigned grid = xcd_grid(cfg.map);
+	if (grid_out)
+		*grid_out = grid;
+	if (!cfg.beta && m > 0)
+		HIP_TRY(hipMemsetAsync(y, 0, (size_t) m * sizeof(T), stream));
+	if (grid == 0)
+		return 0;
+	// lds_window_bytes = bytes of the x window incl. its spare slot; the y window (fp64) follows, 16-byte aligned
+	const int slots = lds_window_bytes / (int) sizeof(T);
+	const int ys_off = (lds_window_bytes + 15) / 16 * 16;
+	const int lds_bytes = ys_off + slots * 8;
+	static int granted[64][2] = {{0}};
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	dev = dev < 0 || dev >= 64 ? 0 : dev;
+	int & have = granted[dev][cfg.nt ? 1 : 0];
+	if (lds_bytes > have)
+	{
+		if (cfg.nt)
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sell_window_sym_kernel<T, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+		else
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sell_window_sym_kernel<T, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+		have = lds_bytes;
+	}
+	if (cfg.nt)
+		hipLaunchKernelGGL((sell_window_sym_kernel<T, S, true>), dim3(grid), dim3(threads), lds_bytes, stream, grp, sdesc, idx, (const T *) val,
+				row_of_sorted, (const T *) x, (T *) y, m, ys_off, cfg.map);
+	else
+		hipLaunchKernelGGL((sell_window_sym_kernel<T, S, false>), dim3(grid), dim3(threads), lds_bytes, stream, grp, sdesc, idx, (const T *) val,
+				row_of_sorted, (const T *) x, (T *) y, m, ys_off, cfg.map);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int
+launch_sell_window_sym(bool f32, int waves_per_slice, int slices_per_group, const int * grp, const int64_t * sdesc, const unsigned short * idx,
+		const void * val, const int * row_of_sorted, const void * x, void * y, int m, int lds_window_bytes, const LaunchCfg & cfg,
+		hipStream_t stream, long * grid_out)
+{
+	const int threads = waves_per_slice * slices_per_group * WAVE;
+	if (threads < WAVE || threads > 1024)
+	{
+		set_error("sell window (symmetric): %d slices x %d waves per workgroup (at most 16 waves)", slices_per_group, waves_per_slice);
+		return 1;
+	}
+	#define SYM_ARGS threads, grp, sdesc, idx, val, row_of_sorted, x, y, m, lds_window_bytes, cfg, stream, grid_out
+	switch (waves_per_slice)
+	{
+		case 1: return f32 ? sell_window_sym_launch_s<float, 1>(SYM_ARGS) : sell_window_sym_launch_s<double, 1>(SYM_ARGS);
+		case 2: return f32 ? sell_window_sym_launch_s<float, 2>(SYM_ARGS) : sell_window_sym_launch_s<double, 2>(SYM_ARGS);
+		case 4: return f32 ? sell_window_sym_launch_s<float, 4>(SYM_ARGS) : sell_window_sym_launch_s<double, 4>(SYM_ARGS);
+	}
+	#undef SYM_ARGS
+	set_error("sell window (symmetric): waves per slice must be 1, 2 or 4 (got %d)", waves_per_slice);
+	return 1;
+}
+
 int
 sell_window_lds_budget()
 {

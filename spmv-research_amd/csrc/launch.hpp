@@ -73,6 +73,11 @@ int launch_sell_window(bool f32, int waves_per_slice, int slices_per_group, cons
 		const void * val, const int * row_of_sorted, const void * x, void * y, int m, int lds_window_bytes, const LaunchCfg & cfg,
 		hipStream_t stream, long * grid_out);
 
+// the same layout holding ONE TRIANGLE of a symmetric matrix: y window in LDS beside the x window, mirrored entries as LDS atomics
+int launch_sell_window_sym(bool f32, int waves_per_slice, int slices_per_group, const int * grp, const int64_t * sdesc, const unsigned short * idx,
+		const void * val, const int * row_of_sorted, const void * x, void * y, int m, int lds_window_bytes, const LaunchCfg & cfg,
+		hipStream_t stream, long * grid_out);
+
 // Sensitivity experiments on the delta layout's index-free modes: SPMV_MI355X_SELL_MODES_OFF, bit 0 = no affine slices (mode 0),
 // bit 1 = no per-slice lane offsets (mode 3), bit 2 = no lane offsets with exceptions (mode 5); such slices then store 8- / 16-bit
 // deltas per lane. Read at every create().

@@ -150,6 +150,45 @@ spmv_mi355x_create(spmv_mi355x_matrix ** out, int format, int precision, long m,
 		return 1;
 	}
 	HIP_TRY(hipSetDevice(device));
+	// ---- symmetric storage in + SELL-C-sigma: the stored triangle itself in the LDS-window layout, when the matrix is banded enough for
+	// a slice group's window of rows and columns to fit LDS (half the matrix stream; kernels_sell_window.hip). Anything else — and every
+	// malformed input, for its error message — goes through the expansion below.
+	if (o.symmetric_input && format == SPMV_MI355X_SELL_C_SIGMA && o.sell_window != 2 && o.sell_delta != 1 && (o.sell_c == 0 || o.sell_c == 64) &&
+	    o.sell_sigma == 0 && m == n && !o.row_begin && !o.row_end && !o.col_filter_mode && row_ptr[0] == 0 && row_ptr[m] == nnz && nnz >= (1L << 16))
+	{
+		bool ok = true;
+		long expanded = 0;
+		#pragma omp parallel for num_threads(spmv::host_threads()) schedule(static, 4096) reduction(&& : ok) reduction(+ : expanded)
+		for (long i = 0; i < m; i++)
+		{
+			ok = ok && row_ptr[i + 1] >= row_ptr[i] && row_ptr[i] >= 0 && row_ptr[i + 1] <= nnz;
+			for (long j = row_ptr[i]; j < row_ptr[i + 1] && ok; j++)
+			{
+				ok = ok && col_idx[j] >= 0 && col_idx[j] < n;
+				expanded += col_idx[j] == i ? 1 : 2;
+			}
+		}
+		// Taken on its own only when the EXPANDED matrix would not stay in the 256 MiB Infinity Cache from launch to launch: measured on the
+		// cant / pwtk twins (49 / 96 MB, cache-resident), symmetric storage halves the footprint and the bytes moved but takes 14.6 against
+		// 9.2 us and 30.9 against 17.3 us — one LDS atomic per entry and a second launch (the y clear) cost more than a stream the caches
+		// serve anyway. opts.sell_window = 1 asks for it regardless.
+		const bool wanted = o.sell_window == 1 || (double) expanded * ((precision == SPMV_MI355X_F32 ? 4 : 8) + 4) > 256.0 * 1024 * 1024;
+		if (ok && wanted && expanded < 0x7fffffffL)
+		{
+			spmv_mi355x_matrix * S = new spmv_mi355x_matrix();
+			init_handle(S, format, precision, device, o, m, n, expanded);
+			const int took = build_sell_symmetric(S, o, row_ptr, col_idx, values);
+			if (took == 0)
+			{
+				*out = S;
+				return 0;
+			}
+			free_all(S);
+			delete S;
+			if (took == 1)
+				return 1;
+		}
+	}
 	// ---- input stage: symmetric expansion, row block / column filter, validation (build_input.hip)
 	LocalCsr in;
 	if (prepare_local_csr(o, m, n, nnz, row_ptr, col_idx, values, in))
@@ -254,7 +293,10 @@ spmv_mi355x_spmv_device_async(spmv_mi355x_matrix * A, const void * x, void * y, 
 					A->merge_num_tiles, A->d_coords, A->d_carry_row, A->d_carry_val, cfg, st, &grid);
 			break;
 		case SPMV_MI355X_SELL_C_SIGMA:
-			rc = A->sell_window
+			rc = A->sell_sym
+			     ? launch_sell_window_sym(A->f32, A->sell_split, A->sellw_ns, A->d_sellw_grp, A->d_sell_desc, (const unsigned short *) A->d_sell_idx, A->d_val,
+					A->d_row_of_sorted, x, y, (int) A->m, A->sellw_lds, cfg, st, &grid)
+			     : A->sell_window
 			     ? launch_sell_window(A->f32, A->sell_split, A->sellw_ns, A->d_sellw_grp, A->d_sell_desc, (const unsigned short *) A->d_sell_idx, A->d_val,
 					A->d_row_of_sorted, x, y, (int) A->m, A->sellw_lds, cfg, st, &grid)
 			     : A->sell_delta

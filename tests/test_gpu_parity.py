@@ -523,6 +523,63 @@ def test_symmetric_input_matches_reference_csr_sym(eng, oracle, case):
                 G.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+def test_symmetric_storage_kernel_on_banded_matrices(eng, oracle, dtype):
+    """Row f4, the traffic-halving half: one stored triangle of a BANDED symmetric matrix in the LDS-window layout, multiplied without
+    expanding it (sell_window_sym_kernel: mirrored additions as LDS atomics, the group's y window added to y with coalesced atomics).
+    Against the oracle's restatement of the reference csr_sym kernel (pinned bit for bit to the reference build, tests/golden) and
+    against the expansion through the general path, to the reordering tolerance; lower and upper triangle; y += A x; the footprint
+    is about half the expanded layout's. A matrix whose mirror scatters (no band) is expanded as before."""
+    import scipy.sparse as sp
+    import spmv_host as H
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    A = H.gen_named("cant", 0.5)
+    m = A["m"]
+    M = sp.csr_matrix((A["values"], A["col_idx"], A["row_ptr"]), shape=(m, m))
+    x = np.random.default_rng(23).uniform(-1, 1, m)
+    for lower, tri, other in ((True, sp.tril(M).tocsr(), sp.tril(M, -1).T), (False, sp.triu(M).tocsr(), sp.triu(M, 1).T)):
+        tri.sort_indices()
+        Ex = (tri + other).tocsr()
+        Ex.sort_indices()
+        rp, ci, a = tri.indptr.astype(np.int32), tri.indices.astype(np.int32), tri.data.astype(np.float64)
+        erp, eci, ea = Ex.indptr.astype(np.int32), Ex.indices.astype(np.int32), Ex.data.astype(np.float64)
+        absrow = abs(Ex) @ np.abs(x)
+        y_sym = oracle.csr_sym_spmv(rp, ci, a, x, dtype)                      # csr_sym.cpp:191-267 restated
+        y_exp = oracle.csr_spmv(erp, eci, ea, x, dtype)
+        S = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma", dtype, symmetric_input=1, sell_window=1)
+        G = eng.Matrix(erp, eci, ea, m, m, "sell_c_sigma", dtype)
+        assert "SELLWS" in S.format_name and S.kernel_info()["name"] == "sell_window_sym_kernel"
+        assert S.nnz == Ex.nnz and S.m == m and S.mem_footprint < 0.6 * G.mem_footprint
+        y = S.spmv(x)
+        if lower:          # the reference kernel ASSIGNS y[i] after row i (csr_sym.cpp:233): right for the lower triangle only, what .mtx files hold
+            check(y, y_sym, absrow, dtype, False, "symmetric storage vs csr_sym oracle")
+        check(y, y_exp, absrow, dtype, False, "symmetric storage vs expansion")
+        # y += A x through the device entry point (beta = 1: no clear)
+        S.upload_x(x)
+        S.upload_y(np.full(m, 2.0))
+        S.spmv_device(S.x_device(), S.y_device(), 1, 0)
+        check(S.download_y() - 2.0, y_exp, absrow + 2.0, dtype, False, "symmetric storage, beta = 1")
+        S.close()
+        G.close()
+    # default options on a cache-resident matrix: expanded (faster there); a matrix without a band: expanded as well
+    S = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma", dtype, symmetric_input=1)
+    assert "SELLWS" not in S.format_name
+    S.close()
+    rng = np.random.default_rng(5)
+    n2 = 60000
+    R = sp.random(n2, n2, density=12.0 / n2, random_state=rng, format="csr")
+    T2 = sp.tril(R + sp.eye(n2)).tocsr()
+    T2.sort_indices()
+    S = eng.Matrix(T2.indptr.astype(np.int32), T2.indices.astype(np.int32), T2.data.astype(np.float64), n2, n2, "sell_c_sigma", dtype,
+                   symmetric_input=1, sell_window=0, sell_sigma=0)
+    assert "SELLWS" not in S.format_name
+    E2 = (T2 + sp.tril(T2, -1).T).tocsr()
+    x2 = rng.uniform(-1, 1, n2)
+    check(S.spmv(x2), oracle.csr_spmv(E2.indptr.astype(np.int32), E2.indices.astype(np.int32), E2.data, x2, dtype), abs(E2) @ np.abs(x2), dtype, False,
+          "symmetric input without a band")
+    S.close()
+
+
 def test_create_rejects_non_monotone_row_ptr_before_sizing_anything(eng):
     """A row_ptr whose lengths go +10 then -10 used to size the filtered copy from the final prefix sum (0) and overflow it while
     writing at the per-row offsets, before the monotonicity check ran (advisor finding, round 1): now refused up front, on every
