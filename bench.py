@@ -638,6 +638,14 @@ def main():
         result["roofline"]["floor"] = {"what": "index-free modes off (SPMV_MI355X_SELL_MODES_OFF=7)", "ms": rf["ms"], "kernel_ms": rf["kernel_ms"],
                                        "stored_bytes_per_nnz": round(tf["mem_footprint"] / max(nnz, 1), 3)}
         del tf
+        # ... and in between: 5 % of the rows out of line (their off-diagonal columns moved by up to +-3): the slices they sit in keep
+        # their lane offsets and carry one signed byte per step for the rows that do not fit (mode 5 of the layout)
+        Aj, _ = load_workload(H, workload, args.scale, 0.05, 3)
+        tj = time_handle(E, torch, Aj, fmt, dts, opts, min(args.steps, 300), args.warmup)
+        rj = roofline_record(workload, dts, tj, with_traffic=False)
+        result["roofline"]["jitter"] = {"what": "5 % of the rows perturbed by +-3 columns (bench.py --jitter 0.05)", "frac": rj["frac"], "ms": rj["ms"],
+                                        "kernel_ms": rj["kernel_ms"], "stored_bytes_per_nnz": round(tj["mem_footprint"] / max(Aj["nnz"], 1), 3)}
+        del Aj, tj
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, workload, dts, A, t["x_host"], t["yh"])
     del A, t
