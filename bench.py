@@ -420,7 +420,7 @@ def run_small_configs(E, torch, H, args):
                         "best_cold_ms": round(best["cold_ms"], 6), "cold_frac": round(B / (best["cold_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                         "cold": "isolated launches, a 1 GiB buffer overwritten before each (bench_spmv.cpp:331-348 CLEAR_CACHES); median of 15"})
         if w in SYMMETRIC_CONFIGS:
-            rec["symmetric_storage"] = symmetric_storage_leg(E, torch, A, dts, steps, warm)
+            rec["symmetric_storage"] = symmetric_storage_leg(E, torch, A, w, dts, steps, warm)
         if not args.no_cpu_baseline:
             # the reference's CPU CSR kernel on the same matrix (whole matrix where it has <= 64 M non-zeros: config 1 IS this on cant)
             saved = args.cpu_baseline_seconds
@@ -432,7 +432,7 @@ def run_small_configs(E, torch, H, args):
     return out
 
 
-def symmetric_storage_leg(E, torch, A, dts, steps, warm):
+def symmetric_storage_leg(E, torch, A, w, dts, steps, warm):
     """Row f4 (KEEP_SYMMETRY builds, csr_sym.cpp): the LOWER triangle of the twin as the stored triangle of a symmetric matrix
     (T + T^t - diag T: the twin mirrored, not the twin itself), multiplied by the symmetric-storage kernel WITHOUT expanding it, beside
     the same symmetric matrix expanded and run through the general SELL path. Fractions are on the EXPANDED matrix's algorithmic bytes."""
@@ -470,11 +470,14 @@ def symmetric_storage_leg(E, torch, A, dts, steps, warm):
            "format": S.format_name, "kernel": S.kernel_info()["name"], "stored_nnz": int(T.nnz), "expanded_nnz": int(Ex.nnz),
            "mem_footprint": S.mem_footprint, "ms": round(wall_ms, 6), "kernel_ms": round(k_ms, 6),
            "frac_on_expanded_bytes": round(B / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "check_max_err_over_abs_row": err,
-           "traffic": None}
+           "traffic": load_traffic(w + ":sym1", S.format_name, dts, "sell_window_sym_kernel")}
     S.close()
     g = time_handle(E, torch, full, "sell_c_sigma", dts, {}, steps, 20, x_host=x_host, min_warm_seconds=warm)
     out["expanded"] = {"format": g["format_name"], "ms": round(g["wall_ms"], 6), "mem_footprint": g["mem_footprint"],
-                       "frac": round(B / (g["wall_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                       "frac": round(B / (g["wall_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                       "traffic": load_traffic(w + ":sym2", g["format_name"], dts, g["kernel"])}
+    if out["traffic"] and out["expanded"]["traffic"]:
+        out["traffic_ratio_to_expanded"] = round(out["traffic"] / out["expanded"]["traffic"], 4)
     return out
 
 

@@ -22,7 +22,7 @@ def kernel_means(d):
                 k = r["Kernel_Name"]
                 # the SpMV kernels only: not the fix-up / search / expansion helpers, not the conversion kernels
                 if "spmv::" not in k or not any(t in k for t in ("csr_scalar_kernel", "csr_vector_kernel", "csr_vector_multi_kernel",
-                        "csr_stream", "csr_window_kernel", "merge_kernel", "sell_kernel", "sell_delta", "sell_window_kernel", "sell_wide_kernel",
+                        "csr_stream", "csr_window_kernel", "merge_kernel", "sell_kernel", "sell_delta", "sell_window_kernel", "sell_window_sym_kernel", "sell_wide_kernel",
                         "coo_kernel", "coo_blocked_kernel")):
                     continue
                 name = k.split("(")[0].replace("void spmv::", "")

@@ -4,12 +4,12 @@
 #   2. the same bench line un-profiled (what the numbers are quoted from)
 #   3. PMC traffic passes (FETCH_SIZE / WRITE_SIZE / TCC_EA0 request sizes / L2 hits) of the named and the best kernel of every config
 set -o pipefail
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 # PMC passes first: the bench lines that follow attach traffic records only when they were collected on the same kernel sources
 if [ -z "$ONLY_BENCH" ]; then
-  bash tools/collect_traffic.sh "nlpkkt240:sell_c_sigma:f64 nlpkkt240:csr_stream:f64 cant:sell_c_sigma:f64 cant:csr_vector:f64 cant:csr_stream:f64 scircuit:csr_vector:f64 scircuit:csr_vector:f64:lanes_per_row=64,rows_per_group=2 pwtk:sell_c_sigma:f32 pwtk:csr_stream:f32 soc-LiveJournal1:coo:f64:col_blocks=-1 soc-LiveJournal1:csr_merge:f64 soc-LiveJournal1:csr_merge:f64:col_blocks=-2"
+  bash tools/collect_traffic.sh "nlpkkt240:sell_c_sigma:f64:placement=1 nlpkkt240:csr_stream:f64:placement=1 cant:sell_c_sigma:f64 cant:csr_vector:f64 cant:csr_stream:f64 cant:sell_c_sigma:f64:sym=1 cant:sell_c_sigma:f64:sym=2 scircuit:csr_vector:f64 scircuit:csr_vector:f64:lanes_per_row=64,rows_per_group=2 pwtk:sell_c_sigma:f32 pwtk:csr_stream:f32 pwtk:sell_c_sigma:f32:sym=1 pwtk:sell_c_sigma:f32:sym=2 soc-LiveJournal1:coo:f64:col_blocks=-1 soc-LiveJournal1:csr_merge:f64 soc-LiveJournal1:csr_merge:f64:col_blocks=-1"
   python tools/collect_traffic.py gpurun_out/traffic gpurun_out/traffic_${ROUND}.json
   cp gpurun_out/traffic_${ROUND}.json profiles/traffic_${ROUND}.json
 fi

@@ -31,6 +31,20 @@ def main():
     npd = np.float64 if args.dtype == "f64" else np.float32
     td = torch.float64 if args.dtype == "f64" else torch.float32
     opts = {k: int(v) for k, v in (o.split("=") for o in args.opt)}
+    sym = opts.pop("sym", 0)
+    if sym:
+        # row f4: the twin's LOWER triangle as the stored triangle of a symmetric matrix — sym=1: multiplied by the symmetric-storage
+        # kernel without expanding it; sym=2: the same symmetric matrix expanded, through the general path (what it is compared with)
+        import scipy.sparse as sp
+        Mx = sp.csr_matrix((A["values"], A["col_idx"], A["row_ptr"]), shape=(A["m"], A["m"]))
+        T = sp.tril(Mx).tocsr()
+        T.sort_indices()
+        Ex = (T + sp.tril(Mx, -1).T).tocsr()
+        Ex.sort_indices()
+        src = T if sym == 1 else Ex
+        A = dict(A, row_ptr=src.indptr.astype(np.int32), col_idx=src.indices.astype(np.int32), values=src.data.astype(np.float64), nnz=int(Ex.nnz))
+        if sym == 1:
+            opts.update(symmetric_input=1, sell_window=1)
     M = E.Matrix(A["row_ptr"], A["col_idx"], A["values"], A["m"], A["n"], args.format, npd, **opts)
     M.upload_x(np.random.default_rng(14).uniform(-1, 1, A["n"]).astype(npd))     # the handle's own, engine-placed x / y (as bench.py)
     xp, yp = M.x_device(), M.y_device()
@@ -49,7 +63,7 @@ def main():
         import bench
         os.makedirs(os.path.dirname(args.meta), exist_ok=True)
         with open(args.meta, "w") as f:
-            json.dump(dict(workload=args.workload, dtype=args.dtype, format=args.format, opts=opts, scale=args.scale, jitter=args.jitter,
+            json.dump(dict(workload=args.workload + (f":sym{sym}" if sym else ""), dtype=args.dtype, format=args.format, opts=opts, scale=args.scale, jitter=args.jitter,
                            modes_off=int(os.environ.get("SPMV_MI355X_SELL_MODES_OFF", "0")), stored_bytes_per_nnz=M.mem_footprint / max(A["nnz"], 1),
                            format_name=M.format_name,
                            kernel=M.kernel_info()["name"], kernel_src_sha=bench.kernel_source_sha(), algorithmic_bytes=B, us_per_launch=ms * 1e3), f)
