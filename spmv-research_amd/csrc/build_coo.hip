@@ -211,47 +211,52 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 			std::vector<unsigned> & E = wg_ent[(size_t) t];
 			std::vector<double> & V = wg_val[(size_t) t];
 			std::vector<int> & Bs = wg_base[(size_t) t];
-			// position p of a batch is entry u = p / 1024 of lane p % 1024: the 64 entries of one wave instruction are 64 consecutive
-			// positions, and the instructions of a batch in sorted order are (u, wave) = (0, 0), (0, 1), ... (0, 15), (1, 0), ...
-			// Every instruction has its own base column (table [batch][wave][u]) and takes sorted entries while column - base < SPAN.
-			size_t k = 0;
-			long lastbase = 0;
-			while (k < tmp.size())
+			// The sorted entries are cut into GROUPS of up to 64 = what one wave instruction gathers; a group has its own base column
+			// (table [batch][wave][u]) and takes sorted entries while column - base < SPAN. Position p of a batch is entry u = p / 1024
+			// of lane p % 1024, so group (u, wave) of batch b sits at b * BATCH + u * 1024 + wave * 64.
+			// The sorted groups fill the batches in order: batch b takes groups 128 b .. 128 b + 127 (K = 8), (u, wave) = (0, 0), (0, 1), ...
+			// (Tried and dropped: K cursors, each walking one K-th of the sorted list, so that a batch touches K short stretches of x
+			// instead of one long one where the entries are sparse — 206-216 against 190 us on the soc-LiveJournal1 twin: every batch then
+			// has a slow sub-batch and the waves wait for it at the barrier.)
+			struct Group { size_t first; int count; int base; };
+			std::vector<Group> groups;
+			for (size_t k = 0; k < tmp.size();)
 			{
-				const size_t b0 = Bs.size();
-				Bs.resize(b0 + (size_t) (NW * KPL), 0);
-				for (long g = 0; g < NW * KPL; g++)
-				{
-					const long u = g / NW, w = g % NW;
-					const long base = k < tmp.size() ? (long) (tmp[k].key >> 32) : lastbase;
-					lastbase = base;
-					Bs[b0 + (size_t) (w * KPL + u)] = (int) base;
-					long fill = 0;
-					for (; fill < 64 && k < tmp.size() && (long) (tmp[k].key >> 32) - base < SPAN; fill++, k++)
-					{
-						E.push_back((unsigned) (((long) (tmp[k].key >> 32) - base) << SLOT_BITS) | (unsigned) (tmp[k].key & 0xffffffffu));
-						if (!uniform)
-							V.push_back(tmp[k].v);
-					}
-					for (; fill < 64; fill++)
-					{
-						E.push_back(spare0 + (unsigned) (fill % SPARE));
-						if (!uniform)
-							V.push_back(0.0);
-					}
-				}
+				const long base = (long) (tmp[k].key >> 32);
+				int fill = 0;
+				const size_t first = k;
+				for (; fill < 64 && k < tmp.size() && (long) (tmp[k].key >> 32) - base < SPAN; fill++, k++)
+					;
+				groups.push_back(Group{first, fill, (int) base});
 			}
-			// the kernel's loop is unrolled over three rotating register sets: whole batches of padding up to a multiple of 3
-			while ((Bs.size() / (size_t) (NW * KPL)) % 3)
+			const long GPB = NW * KPL;                                  // groups per batch
+			long nbt = ((long) groups.size() + GPB - 1) / GPB;
+			nbt = (nbt + 2) / 3 * 3;                                    // the kernel's loop is unrolled over three rotating register sets
+			E.assign((size_t) (nbt * BATCH), 0u);
+			if (!uniform)
+				V.assign((size_t) (nbt * BATCH), 0.0);
+			Bs.assign((size_t) (nbt * GPB), 0);
+			int lastbase = groups.empty() ? 0 : groups[0].base;
+			for (long slot = 0; slot < nbt * GPB; slot++)
 			{
-				const int last = Bs.back();
-				Bs.resize(Bs.size() + (size_t) (NW * KPL), last);
-				for (long fill = 0; fill < BATCH; fill++)
+				const long bt = slot / GPB, u = (slot % GPB) / NW, w = slot % NW;
+				const size_t at = (size_t) (bt * BATCH + u * 1024 + w * 64);
+				int fill = 0;
+				if (slot < (long) groups.size())
 				{
-					E.push_back(spare0 + (unsigned) (fill % SPARE));
-					if (!uniform)
-						V.push_back(0.0);
+					const Group & g = groups[(size_t) slot];
+					lastbase = g.base;
+					for (; fill < g.count; fill++)
+					{
+						const Ent & e = tmp[g.first + (size_t) fill];
+						E[at + (size_t) fill] = (unsigned) (((long) (e.key >> 32) - g.base) << SLOT_BITS) | (unsigned) (e.key & 0xffffffffu);
+						if (!uniform)
+							V[at + (size_t) fill] = e.v;
+					}
 				}
+				Bs[(size_t) ((bt * NW + w) * KPL + u)] = lastbase;
+				for (; fill < 64; fill++)
+					E[at + (size_t) fill] = spare0 + (unsigned) (fill % SPARE);       // padding: column offset 0, a spare LDS slot, value 0
 			}
 		}
 	}
