@@ -60,10 +60,7 @@ typedef struct {
 	                        /* CSR_STREAM: the same field holds ROWS PER WAVEFRONT (4,8,16,32,64); 0 = auto          */
 	int  sell_split;        /* SELL delta format: wavefronts sharing one 64-row slice (1, 2 or 4); 0 = auto by slice count */
 	int  sell_c;            /* SELL: rows per slice (16, 32, 64, or 256 = the BSC library's, sell_c_s.cpp:58-60); 0 = 64         */
-	int  sell_sigma;        /* SELL: sort window in rows (multiple of sell_c); 0 = 16384 (sell_c_s.cpp:58-60). A window is sorted by
-	                           row length, descending, stable (radix_sort.c:103-122). With 0 the delta layout additionally orders rows of
-	                           EQUAL length by the class of their column pattern, so that rows of one stencil kind share slices and a row
-	                           out of line does not sit among 63 regular ones; name a sigma to get the reference's order               */
+	int  sell_sigma;        /* SELL: sort window in rows (multiple of sell_c); 0 = 16384 (sell_c_s.cpp:58-60)      */
 	int  merge_items;       /* MERGE: merge items per thread (5,7,9,11,13); COO: entries per lane (2,4,8); 0 = default */
 	int  xcd_remap;         /* tile order over the 8 XCDs: 0 = auto, 1 = contiguous work-balanced ranges, 2 = off,
 	                           3 = chunks of 64 tiles dealt round-robin to the XCDs                                */

@@ -144,7 +144,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 		std::vector<int64_t> val_ptr;
 		int64_t nnz_ext = 0, idx_bytes = 0;
 		void * d_val = nullptr;
-		if (sell_delta_convert_device(A->f32, m, A->n, A->nnz, sigma, A->sell_regroup, rp, ci, va, &A->d_row_of_sorted, &A->d_sell_desc, &A->d_sell_idx,
+		if (sell_delta_convert_device(A->f32, m, A->n, A->nnz, sigma, rp, ci, va, &A->d_row_of_sorted, &A->d_sell_desc, &A->d_sell_idx,
 				&d_val, val_ptr, A->sell_mode_slices, &nnz_ext, &idx_bytes))
 			return 1;
 		A->d_val = d_val;
@@ -162,20 +162,6 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 	for (long w = 0; w < num_windows; w++)
 	{
 		long s = w * sigma, e = std::min(m, s + sigma);
-		if (A->sell_regroup)
-		{
-			// length descending, then pattern class ascending, stable: the key and the order of convert_sell.hip's row_key_kernel + radix sort
-			std::vector<std::pair<unsigned long long, int>> keyed((size_t) (e - s));
-			for (long i = s; i < e; i++)
-			{
-				const int len = rp[i + 1] - rp[i];
-				keyed[(size_t) (i - s)] = {((unsigned long long) (unsigned) len << 32) | (unsigned long long) (0xffffffffu - sell_pattern_class(ci + rp[i], len)), (int) i};
-			}
-			std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<unsigned long long, int> & p, const std::pair<unsigned long long, int> & q) { return p.first > q.first; });
-			for (long i = s; i < e; i++)
-				row_of_sorted[i] = keyed[(size_t) (i - s)].second;
-			continue;
-		}
 		int maxlen = 0;
 		for (long i = s; i < e; i++)
 			maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
@@ -584,9 +570,6 @@ build_sell_family(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const int 
 	A->sell_c = C;
 	A->sell_sigma = sigma;
 	A->sell_delta = (C == 64) && (o.sell_delta != 2);      // 0 = auto (on for 64-row slices), 1 = on, 2 = off
-	// rows of equal length ordered by pattern class inside a sigma window: on for the delta layout unless the caller names a sigma (then
-	// the order is the reference's, radix_sort.c:103-122: stable by length alone — what the a6' / a7 layout parity tests compare)
-	A->sell_regroup = A->sell_delta && o.sell_sigma == 0 && !(getenv("SPMV_MI355X_SELL_REGROUP") && atoi(getenv("SPMV_MI355X_SELL_REGROUP")) == 0);
 	A->convert_on_device = o.convert_on != 2 && !getenv("SPMV_MI355X_HOST_CONVERT");
 	{
 		// waves per slice: enough wavefronts to occupy 256 CUs several times over
@@ -697,13 +680,12 @@ build_sell_delta_resident(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, co
 	A->sell_c = C;
 	A->sell_sigma = sigma;
 	A->sell_delta = true;
-	A->sell_regroup = o.sell_sigma == 0 && !(getenv("SPMV_MI355X_SELL_REGROUP") && atoi(getenv("SPMV_MI355X_SELL_REGROUP")) == 0);
 	A->convert_on_device = true;
 	A->sell_split = S;
 	std::vector<int64_t> val_ptr;
 	int64_t nnz_ext = 0, idx_bytes = 0;
 	void * d_val = nullptr;
-	if (sell_delta_convert_resident(A->f32, m, A->n, A->nnz, sigma, A->sell_regroup, d_rp, d_ci, d_va, &A->d_row_of_sorted, &A->d_sell_desc, &A->d_sell_idx, &d_val,
+	if (sell_delta_convert_resident(A->f32, m, A->n, A->nnz, sigma, d_rp, d_ci, d_va, &A->d_row_of_sorted, &A->d_sell_desc, &A->d_sell_idx, &d_val,
 			val_ptr, A->sell_mode_slices, &nnz_ext, &idx_bytes))
 		return 1;
 	A->d_val = d_val;

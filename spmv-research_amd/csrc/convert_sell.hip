@@ -22,16 +22,13 @@ namespace spmv {
 
 constexpr int CV_BLOCK = 256;
 
-// sort key of a row inside its sigma window, for a DESCENDING stable sort: length first; with `regroup` then the pattern class ascending
 __global__ __launch_bounds__(CV_BLOCK) void
-row_key_kernel(const int * __restrict__ rp, const int * __restrict__ ci, int m, int regroup, unsigned long long * __restrict__ key, int * __restrict__ ids)
+row_length_kernel(const int * __restrict__ rp, int m, int * __restrict__ len, int * __restrict__ ids)
 {
 	const int i = blockIdx.x * CV_BLOCK + threadIdx.x;
 	if (i < m)
 	{
-		const int len = rp[i + 1] - rp[i];
-		const unsigned cls = regroup ? sell_pattern_class(ci + rp[i], len) : 0u;
-		key[i] = ((unsigned long long) (unsigned) len << 32) | (unsigned long long) (0xffffffffu - cls);
+		len[i] = rp[i + 1] - rp[i];
 		ids[i] = i;
 	}
 }
@@ -322,7 +319,7 @@ struct Scratch {
 // Outputs (device, owned by the caller on success): row_of_sorted[m], desc[2*(slices+1)], idx[idx_bytes+1024], val[nnz_ext
 // + STREAM_SLACK] of the handle's precision. Host outputs: val_ptr (slices+1, for the tile map), mode counts, sizes.
 int
-sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma, bool regroup, const int * rp, const int * ci,
+sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp, const int * ci,
 		const double * va, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
 		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out)
 {
@@ -330,9 +327,8 @@ sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma,
 	const long num_slices = (m + WAVE - 1) / WAVE;
 	const long num_windows = (m + sigma - 1) / sigma;
 	Scratch tmp;
-	int * ids, * win_off;
-	unsigned long long * key, * key_sorted;
-	if (tmp.get(&key, (size_t) m * 8) || tmp.get(&key_sorted, (size_t) m * 8) || tmp.get(&ids, (size_t) m * 4) ||
+	int * len, * len_sorted, * ids, * win_off;
+	if (tmp.get(&len, (size_t) m * 4) || tmp.get(&len_sorted, (size_t) m * 4) || tmp.get(&ids, (size_t) m * 4) ||
 	    tmp.get(&win_off, (size_t) (num_windows + 1) * 4))
 		return 1;
 	int * row_of_sorted = nullptr;
@@ -341,23 +337,21 @@ sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma,
 	out_guard.ptrs.push_back(row_of_sorted);
 	HIP_TRY(hipMemset(row_of_sorted, 0, (size_t) std::max<long>(m, 1) * 4 + STREAM_SLACK * 4));
 
-	// 1. sigma-window sort by length, descending, stable (radix_sort.c:103-122 semantics); with `regroup` rows of equal length are
-	// then ordered by pattern class (the low 32 bits of the key take part in the sort)
+	// 1. sigma-window sort by length, descending, stable
 	if (m > 0)
 	{
-		hipLaunchKernelGGL(row_key_kernel, dim3((unsigned) ((m + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0, rp, ci, (int) m, regroup ? 1 : 0, key, ids);
+		hipLaunchKernelGGL(row_length_kernel, dim3((unsigned) ((m + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0, rp, (int) m, len, ids);
 		hipLaunchKernelGGL(window_offsets_kernel, dim3((unsigned) ((num_windows + 1 + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0,
 				m, sigma, num_windows, win_off);
 		HIP_TRY(hipGetLastError());
-		const int begin_bit = regroup ? 0 : 32;
 		size_t bytes = 0;
-		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, bytes, key, key_sorted, ids, row_of_sorted, (int) m,
-				(int) num_windows, win_off, win_off + 1, begin_bit, 64, (hipStream_t) 0));
+		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, bytes, len, len_sorted, ids, row_of_sorted, (int) m,
+				(int) num_windows, win_off, win_off + 1, 0, 32, (hipStream_t) 0));
 		void * sort_tmp;
 		if (tmp.get(&sort_tmp, bytes))
 			return 1;
-		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(sort_tmp, bytes, key, key_sorted, ids, row_of_sorted, (int) m,
-				(int) num_windows, win_off, win_off + 1, begin_bit, 64, (hipStream_t) 0));
+		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(sort_tmp, bytes, len, len_sorted, ids, row_of_sorted, (int) m,
+				(int) num_windows, win_off, win_off + 1, 0, 32, (hipStream_t) 0));
 	}
 
 	// 2. slice shapes   3. offsets
@@ -435,7 +429,7 @@ sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma,
 
 // The same from HOST arrays: upload, convert, drop the uploaded copy.
 int
-sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, bool regroup, const int * rp_host, const int * ci_host,
+sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
 		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
 		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out)
 {
@@ -455,7 +449,7 @@ sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, b
 		HIP_TRY(hipMemcpy(ci, ci_host, (size_t) nnz * 4, hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(va, va_host, (size_t) nnz * 8, hipMemcpyHostToDevice));
 	}
-	return sell_delta_convert_resident(f32, m, n_cols, nnz, sigma, regroup, rp, ci, va, d_row_of_sorted_out, d_desc_out, d_idx_out, d_val_out, val_ptr_host,
+	return sell_delta_convert_resident(f32, m, n_cols, nnz, sigma, rp, ci, va, d_row_of_sorted_out, d_desc_out, d_idx_out, d_val_out, val_ptr_host,
 			mode_counts, nnz_ext_out, idx_bytes_out);
 }
 

@@ -59,7 +59,6 @@ struct spmv_mi355x_matrix {
 	int64_t * d_slice_ptr = nullptr;
 	int * d_row_of_sorted = nullptr;
 	bool sell_delta = false;               // delta-compressed column indices (C = 64 only)
-	bool sell_regroup = false;             // rows of equal length ordered by pattern class inside a sigma window (delta layout, default sigma)
 	bool convert_on_device = true;         // build the delta layout on the GPU (convert_sell.hip) or on the host
 	int sell_split = 1;                    // waves sharing one slice (delta format): 1, 2 or 4
 	int64_t * d_sell_desc = nullptr;

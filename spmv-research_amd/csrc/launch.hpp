@@ -88,26 +88,13 @@ sell_modes_off()
 	return e ? atoi(e) & 7 : 0;
 }
 
-// Class of a row's column pattern: FNV-1a over the columns relative to the row's first (c_k - c_0, k >= 1). Rows of one kind of a
-// stencil (column = row + const_k) share it; host and device builders compute the same 32 bits.
-__host__ __device__ inline unsigned
-sell_pattern_class(const int * __restrict__ cols, int len)
-{
-	unsigned h = 2166136261u;
-	for (int k = 1; k < len; k++)
-		h = (h ^ (unsigned) (cols[k] - cols[0])) * 16777619u;
-	return h;
-}
-
 // CSR -> SELL-64-sigma-delta on the GPU (convert_sell.hip); outputs are device arrays owned by the caller
-// regroup: inside a sigma window rows of equal length are ordered by the CLASS of their column pattern (sell_pattern_class) — rows of one
-// stencil kind end up next to each other, a row out of line (boundary, perturbed) no longer sits in the middle of 63 regular ones
-int sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, bool regroup, const int * rp_host, const int * ci_host,
+int sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
 		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
 		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out);
 
 // the same on a CSR already resident in device memory (rp, ci, va are device pointers; va fp64)
-int sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma, bool regroup, const int * rp, const int * ci,
+int sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp, const int * ci,
 		const double * va, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
 		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out);
 

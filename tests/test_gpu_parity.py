@@ -304,7 +304,7 @@ def test_formats_report_footprint(eng):
     plain_fp = A.mem_footprint
     A.close()
     # delta-compressed indices: same rows / values / (decoded) columns, smaller footprint on a banded matrix
-    B = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", np.float32, sell_c=64, sell_delta=1, sell_sigma=16384)   # a named sigma: the reference's order
+    B = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", np.float32, sell_c=64, sell_delta=1)
     layd = B.sell_layout()
     assert B.mem_footprint < plain_fp
     np.testing.assert_array_equal(layd["row_of_sorted"], lay["row_of_sorted"])
@@ -403,26 +403,10 @@ def test_lane_offsets_with_exceptions(eng, oracle, monkeypatch, frac, span):
     x = np.random.default_rng(17).uniform(-1, 1, n)
     for dtype in (np.float64, np.float32):
         y_ref = oracle.csr_spmv(rp, ci, a, x, dtype, num_threads=1)
-        # default sigma: rows of equal length are also ordered by pattern class (host and GPU builders alike) — the rows out of line
-        # gather between the classes and most slices stay of one pattern; a named sigma keeps the reference's order
-        Hr = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_split=1, convert_on=2)
-        Dr = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_split=1, convert_on=1)
-        lh, ld = Hr.sell_layout(), Dr.sell_layout()
-        assert Dr.mem_footprint == Hr.mem_footprint
-        for k in ("row_of_sorted", "slice_ptr", "col", "val"):
-            np.testing.assert_array_equal(ld[k], lh[k], err_msg="regrouped " + k)
-        assert sorted(ld["row_of_sorted"].tolist()) == list(range(m))
-        np.testing.assert_array_equal(Dr.spmv(x), y_ref)
-        np.testing.assert_array_equal(Hr.spmv(x), y_ref)
-        regrouped = Dr.mem_footprint
-        Hr.close()
-        Dr.close()
         Hm = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=16384, sell_split=1, convert_on=2)
         Dm = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=16384, sell_split=1, convert_on=1)
         lh, ld = Hm.sell_layout(), Dm.sell_layout()
         assert Dm.mem_footprint == Hm.mem_footprint
-        if frac <= 0.25:
-            assert regrouped <= Dm.mem_footprint            # fewer index bytes with the rows of one kind next to each other
         for k in ("row_of_sorted", "slice_ptr", "col", "val"):
             np.testing.assert_array_equal(ld[k], lh[k], err_msg=k)
         # the decoded layout holds the CSR's columns: slice s, step k, lane r = entry k of sorted row 64 s + r
