@@ -121,6 +121,10 @@ def parse(argv=None):
                          "host copy of the matrix never exceeds a piece; 0 = the whole block at once")
     ap.add_argument("--piece-handles", action="store_true",
                     help="N>1: one handle per piece instead of one handle converted from the pieces in device memory (tests)")
+    ap.add_argument("--placement", type=int, default=3, choices=[0, 1, 3],
+                    help="opts.placement of the headline handle: 0 = plain allocations, 1 = vectors from the engine's pools, 3 = pools + the search over "
+                         "the matrix arrays (a few seconds of setup; boxes differ in where the driver puts a process's first allocations: "
+                         "profiles/r03_placement_walk.txt). The small configs always run with 1.")
     ap.add_argument("--idle-after-placement", type=float, default=0.0,
                     help="extra seconds without launches after the engine has placed the vectors (the driver clears the ballast the one "
                          "walk returned in the background; the settle phase runs through it; profiles/r02_placement.md §6)")
@@ -301,6 +305,7 @@ def time_handle(E, torch, A, fmt, dts, opts, steps, warmup, x_host=None, min_war
     t0 = time.time()
     opts = dict(opts)
     opts.setdefault("placement", 1)          # vectors from the engine's pools (csrc/placement.hip): opt-in, and bench.py opts in
+    opts.setdefault("placement_budget_gib", 160)   # this process owns the device: the one walk may go deep before it gives up
     M = E.Matrix(A["row_ptr"], A["col_idx"], A["values"], m, n, fmt, np_dtype, **opts)
     t_conv = time.time() - t0
     # the handle's own x / y pair: allocated and PLACED by the engine (csrc/placement.hip — where y lives relative to the value
@@ -605,6 +610,7 @@ def main():
     # a short sample (the driver's --steps 20 is 25 ms of a kernel whose level moves by a few % over tenths of a second) is timed as
     # 5 windows of K steps, each in its own synchronize bracket; the line carries the MEDIAN window and the spread
     windows = 5 if args.steps < 200 else 1
+    opts.setdefault("placement", args.placement)
     t = time_handle(E, torch, A, fmt, dts, opts, args.steps, args.warmup, min_warm_seconds=0.25 if small else 0.0,
                     idle_after_placement=args.idle_after_placement, windows=windows)
     ms_per_step = t["wall_ms"]                    # synchronize bracket around exactly K launches (the median window of `windows`)
@@ -629,6 +635,7 @@ def main():
         "roofline": roofline_record(workload, dts, t, with_traffic=args.scale == 1.0 and not args.jitter and not args.index_modes_off),
         "check_max_err_over_abs_row": t["check"],
         "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t["convert_s"], 2), "upload_x_place_vectors": round(t["place_s"], 2)},
+        "placement": E.placement_info(torch.cuda.current_device()),
     }
     if workload == "nlpkkt240" and fmt == "sell_c_sigma" and not args.index_modes_off and not args.jitter and args.scale == 1.0:
         # the other end of the headline: the same matrix with every index-free mode of the delta layout switched off (8/16-bit deltas per

@@ -78,7 +78,8 @@ typedef struct {
 	int  col_filter_mode;   /* 0 = keep all, 1 = keep columns inside [col_begin,col_end), 2 = keep columns outside     */
 	int  sell_delta;        /* SELL with 64-row slices: column indices stored as one base per step + 8/16-bit deltas per lane
 	                           where they fit (lossless, bit-identical results): 0 = auto (on when sell_c = 64), 1 = on, 2 = off */
-	int  convert_on;        /* where the SELL delta layout is built from the CSR: 0 = auto (GPU), 1 = GPU (csrc/convert_sell.hip),
+	int  convert_on;        /* where the layouts with a GPU builder (SELL delta, SELL LDS-window: csrc/convert_sell.hip; the entry arrays of
+	                           the column-blocked layout: csrc/convert_coo.hip) are built from the CSR: 0 = auto (GPU), 1 = GPU,
 	                           2 = host (OpenMP; kept as the checker — both produce the same bytes)                    */
 	int  symmetric_input;   /* 1 = the CSR arrays hold ONE triangle of a symmetric matrix (KEEP_SYMMETRY builds of the harness:
 	                           csr_to_format(..., symmetric = 1, symmetry_expanded = 0), csr_sym.cpp:118-123); the product is
@@ -108,7 +109,7 @@ typedef struct {
 	                           of a process that asks makes ONE walk through the device's free memory to find them), 2 = off,
 	                           3 = 1 + a search over the handle's matrix arrays (worth 1-2 %, ~500 launches).
 	                           SPMV_MI355X_PLACEMENT in the environment overrides: 0 off, 1 on, 2 on + log on stderr, 3, 4 (diagnostic) */
-	int  placement_budget_gib;  /* transient memory the walk may hold, GiB (0 = 96; it never takes the device's last 8 GiB)              */
+	int  placement_budget_gib;  /* transient memory the walk may hold, GiB (0 = 160; it never takes the device's last 8 GiB)             */
 } spmv_mi355x_opts;
 
 /* ---- library / device ------------------------------------------------------------------------------------ */
@@ -183,11 +184,11 @@ int  spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host);      /* 
 /* The 288 GiB of an MI355X behave as 32 GiB blocks that fall into classes, and the same kernel on the same matrix and x takes 1.28 or
  * 1.46 ms (nlpkkt240 twin) depending only on whether y lives in a block of the same class as the value array; which memory an
  * allocation gets is the driver's choice (profiles/r02_placement.md). With opts.placement = 1 (or SPMV_MI355X_PLACEMENT
- * >= 1) the engine keeps, per process and device, two VECTOR POOLS (1-4 GiB each) in blocks of different class: the first handle that
- * needs a vector of 8 MiB or more walks the device's free memory once — candidates 16 GiB of ballast apart, timed with the handle's
- * own kernel, until one differs from the first by 4 %; at most opts.placement_budget_gib (96) of ballast, returned when the walk
- * ends — and every later vector of any handle is a slice of the pool in which that handle's kernel runs faster (two trials of six
- * launches). The handle's own pair (spmv_mi355x_x_device / y_device, used by spmv_mi355x_spmv) is placed this way; output_alloc /
+ * >= 1) the engine keeps, per process and device, two to four VECTOR POOLS (1-4 GiB each) in blocks of different class: the first
+ * handle that needs a vector of 8 MiB or more walks the device's free memory once — candidates 16 GiB of ballast apart, timed with the
+ * handle's own kernel; one that differs by 1.5 % from every candidate kept so far is kept; the walk ends three candidates after the
+ * last new class; at most opts.placement_budget_gib (160) of ballast, returned when the walk ends — and every later vector of any
+ * handle is a slice of the pool in which that handle's kernel runs fastest (one trial of six launches per pool). The handle's own pair (spmv_mi355x_x_device / y_device, used by spmv_mi355x_spmv) is placed this way; output_alloc /
  * input_alloc give callers of the device-pointer entry points the same for vectors the handle's SpMV writes / reads (bytes >= (rows +
  * 64) resp. cols values; smaller, under 8 MiB or with placement off: a plain allocation). Zero-filled. Free with output_free.
  * OFF by default: the walk holds tens of GiB for a fraction of a second, its free-memory check is racy against other processes on the
@@ -197,7 +198,15 @@ int  spmv_mi355x_upload_y(spmv_mi355x_matrix * A, const void * y_host);      /* 
 int  spmv_mi355x_output_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out);
 int  spmv_mi355x_input_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out);
 int  spmv_mi355x_output_free(void * p);
+/* The search over the handle's MATRIX arrays that opts.placement = 3 runs for the handle's own vector pair, for a caller's pair: every
+ * array of 16 MiB .. 8 GiB is tried at up to ten sites 16 GiB of ballast apart (a device copy and six launches of y = A x per trial; y is
+ * overwritten) and stays where the kernel ran fastest if that beats where it was by 2 %. Same budget and the same caveats as the walk. */
+int  spmv_mi355x_place_arrays(spmv_mi355x_matrix * A, const void * x_dev, void * y_dev);
 int  spmv_mi355x_placement_release(int device /* -1: every device */);
+/* what the walk of a device found: state 0 = none made yet, 1 = pools of different block class kept, 2 = no contrast inside the budget
+ * (plain allocations); candidates timed, GiB of ballast held at its deepest, the number of pools, the walking handle's kernel time (us)
+ * with y in each */
+int  spmv_mi355x_placement_info(int device, int * state_out, int * candidates_out, long * walked_gib_out, int * pools_out, double us_out[4]);
 
 /* ---- solver callers of spmv() ---------------------------------------------------------------- */
 /* Device-resident replacements for the reference's two Krylov drivers, which call MF->spmv() with a vector that changes
@@ -279,6 +288,12 @@ const char * spmv_mi355x_partitioned_exchange(const spmv_mi355x_partitioned * P)
 double spmv_mi355x_partitioned_mem_footprint(const spmv_mi355x_partitioned * P);
 
 /* ---- format introspection for parity tests (host copies of the converted arrays) -------------------------- */
+/* One stored array of the LDS-window SELL layout ("val", "idx", "desc", "row_of_sorted", "groups") or of the column-blocked layout
+ * ("entries", "val", "batch_base", "batch_ptr", "chunk_ptr", "chunk_row", "wg_rows", "range_row", "range_long", "long_row") exactly as it
+ * lies in device memory: a malloc'ed copy (free with spmv_mi355x_free). For the tests that hold the host and the GPU builder of a
+ * layout to the same bytes, and for diagnostics. */
+int  spmv_mi355x_stored_array(const spmv_mi355x_matrix * A, const char * name, void ** out, size_t * bytes_out);
+
 /* SELL-C-sigma layout: any out pointer may be NULL. Arrays are malloc'ed copies; free with spmv_mi355x_free().
  * For delta-compressed handles the column array is DECODED back to the plain column-major layout. */
 int  spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma_out, long * num_slices_out,

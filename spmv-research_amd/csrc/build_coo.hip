@@ -169,23 +169,34 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 	const long NW = 1024 / 64, KPL = BATCH / 1024;                 // waves per workgroup, entries per lane and batch
 	const long SPAN = col_blocks > 0 ? std::max<long>(1, std::min<long>((n + col_blocks - 1) / col_blocks, 1L << (32 - SLOT_BITS))) : 1L << (32 - SLOT_BITS);
 	std::vector<int> wg_rows((size_t) NT, 0);
+	for (long t = 0; t < NT; t++)
+		wg_rows[(size_t) t] = (int) ((chunk_ptr[(size_t) t + 1] - chunk_ptr[(size_t) t]) * CH + (range_long[(size_t) (t / WGS) + 1] - range_long[(size_t) (t / WGS)]));
+	const long GHOST = 2;           // the kernel loads entries and base columns two batches ahead without clamping: two all-zero batches behind the last
+	std::vector<int> batch_ptr((size_t) NT + 1, 0);
+	const bool on_device = A->convert_on_device && NT <= (1L << 17) && SLOT_BITS == 15;
+	if (on_device)
+	{
+		// the GPU builder (convert_coo.hip): the same bytes without the host's sorts
+		if (blocked_entries_convert_device(A->f32, uniform, lm, lnnz, rp, ci, va, NR, WGS, CH, range_row, range_long, long_row, chunk_ptr, chunk_row, wg_rows, SPAN, BATCH,
+				SLOT_BITS, SPARE, GHOST, batch_ptr, &A->d_coob_ent, &A->d_val, &A->d_coob_batch_base))
+			return 1;
+	}
 	struct Ent { unsigned long long key; double v; };
 	std::vector<std::vector<unsigned>> wg_ent((size_t) NT);
 	std::vector<std::vector<double>> wg_val((size_t) NT);
 	std::vector<std::vector<int>> wg_base((size_t) NT);
-	long placed = 0;
+	long placed = on_device ? lnnz : 0;
 	#pragma omp parallel num_threads(spmv::host_threads()) reduction(+ : placed)
 	{
 		std::vector<Ent> tmp;
 		#pragma omp for schedule(dynamic, 4)
-		for (long t = 0; t < NT; t++)
+		for (long t = 0; t < (on_device ? 0 : NT); t++)
 		{
 			const long r = t / WGS, j = t % WGS;
 			const long r1 = range_row[r + 1];
 			const long mine = chunk_ptr[(size_t) t + 1] - chunk_ptr[(size_t) t];
 			const int * cr = chunk_row.data() + chunk_ptr[(size_t) t];
 			const long nlong = range_long[r + 1] - range_long[r];
-			wg_rows[(size_t) t] = (int) (mine * CH + nlong);
 			const unsigned spare0 = (unsigned) (mine * CH + nlong);          // first spare slot
 			// the workgroup's entries as (first, last, LDS slot) spans: its chunk rows, then its pieces of the split rows
 			tmp.clear();
@@ -265,11 +276,11 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 		set_error("column-blocked layout: %ld entries placed, %ld expected", placed, lnnz);
 		return 1;
 	}
-	std::vector<int> batch_ptr((size_t) NT + 1, 0);
 	int max_rows = 0;
 	for (long t = 0; t < NT; t++)
 	{
-		batch_ptr[(size_t) t + 1] = batch_ptr[(size_t) t] + (int) (wg_base[(size_t) t].size() / (size_t) (NW * KPL));
+		if (!on_device)
+			batch_ptr[(size_t) t + 1] = batch_ptr[(size_t) t] + (int) (wg_base[(size_t) t].size() / (size_t) (NW * KPL));
 		max_rows = std::max(max_rows, wg_rows[(size_t) t]);
 	}
 	const long NB = batch_ptr[(size_t) NT];
@@ -286,13 +297,11 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 					range_row[r], range_row[r + 1], ent_r, range_long[r + 1] - range_long[r], mn, (double) sum / WGS, mx, (double) ent_r / ((double) sum * BATCH),
 					*std::min_element(wg_rows.begin() + r * WGS, wg_rows.begin() + (r + 1) * WGS), *std::max_element(wg_rows.begin() + r * WGS, wg_rows.begin() + (r + 1) * WGS));
 		}
-	// the kernel loads entries and base columns two batches ahead without clamping: two all-zero batches behind the last
-	const long GHOST = 2;
-	std::vector<int> batch_base((size_t) ((NB + GHOST) * NW * KPL), 0);
-	std::vector<unsigned> ent((size_t) ((NB + GHOST) * BATCH), 0u);
-	std::vector<double> pval(uniform ? 0 : (size_t) ((NB + GHOST) * BATCH), 0.0);
+	std::vector<int> batch_base(on_device ? 0 : (size_t) ((NB + GHOST) * NW * KPL), 0);
+	std::vector<unsigned> ent(on_device ? 0 : (size_t) ((NB + GHOST) * BATCH), 0u);
+	std::vector<double> pval(uniform || on_device ? 0 : (size_t) ((NB + GHOST) * BATCH), 0.0);
 	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4)
-	for (long t = 0; t < NT; t++)
+	for (long t = 0; t < (on_device ? 0 : NT); t++)
 	{
 		const size_t b0 = (size_t) batch_ptr[(size_t) t];
 		std::copy(wg_base[(size_t) t].begin(), wg_base[(size_t) t].end(), batch_base.begin() + b0 * (size_t) (NW * KPL));
@@ -305,12 +314,13 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 	const long lext = (NB + GHOST) * BATCH;        // stored entries, padding and the two ghost batches included
 	if (upload_ints(wg_rows.data(), wg_rows.size(), &A->d_coob_wg_rows) || upload_ints(range_row.data(), range_row.size(), &A->d_coob_range_row) ||
 	    upload_ints(chunk_ptr.data(), chunk_ptr.size(), &A->d_coob_chunk_ptr) || upload_ints(chunk_row.data(), chunk_row.size(), &A->d_coob_chunk_row) ||
-	    upload_ints(batch_ptr.data(), batch_ptr.size(), &A->d_coob_batch_ptr) || upload_ints(batch_base.data(), batch_base.size(), &A->d_coob_batch_base) ||
+	    upload_ints(batch_ptr.data(), batch_ptr.size(), &A->d_coob_batch_ptr) ||
 	    upload_ints(range_long.data(), range_long.size(), &A->d_coob_range_long) || upload_ints(long_row.data(), long_row.size(), &A->d_coob_long_row) ||
-	    dev_alloc_bytes(&A->d_coob_carry, (size_t) std::max<long>(NL, 1) * WGS * A->vbytes) ||
-	    upload_bytes(ent.data(), (size_t) lext * 4, 64, (void **) &A->d_coob_ent))
+	    dev_alloc_bytes(&A->d_coob_carry, (size_t) std::max<long>(NL, 1) * WGS * A->vbytes))
 		return 1;
-	if (!uniform)
+	if (!on_device && (upload_ints(batch_base.data(), batch_base.size(), &A->d_coob_batch_base) || upload_bytes(ent.data(), (size_t) lext * 4, 64, (void **) &A->d_coob_ent)))
+		return 1;
+	if (!uniform && !on_device)
 	{
 		if (A->f32)
 		{
@@ -332,6 +342,7 @@ build_blocked_layout(spmv_mi355x_matrix * A, const int * rp, const int * ci, con
 	A->coob_ranges = (int) NR;
 	A->coob_batches = NB;
 	A->coob_chunk_rows = (int) CH;
+	A->coob_chunks = (long) chunk_row.size();
 	A->coob_num_long = (int) NL;
 	A->coob_lds = (int) (((long) (std::max(max_rows, 1) + SPARE) * 8 + 15) / 16 * 16);      // fp64 slots for both precisions
 	A->cfg.map = xcd_map_uniform(1, 0);

@@ -401,6 +401,30 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 	const long num_slices = (m + C - 1) / C;
 	const long num_groups = (num_slices + NS - 1) / NS;
 	const long sigma = (long) NS * C;
+	if (A->convert_on_device)
+	{
+		// the GPU builder (convert_sell.hip): the same bytes, without the host passes over the non-zeros
+		std::vector<int64_t> sdesc;
+		int max_w = 0;
+		const int took = sell_window_convert_device(A->f32, m, (long) rp[m], NS, sym, lds_budget_bytes, rp, ci, va, &A->d_sellw_grp, &A->d_row_of_sorted, &A->d_sell_desc,
+				(unsigned short **) &A->d_sell_idx, &A->d_val, sdesc, &max_w);
+		if (took)
+			return took;
+		const int64_t nnz_ext = sdesc[2 * (size_t) num_slices], idx_count = sdesc[2 * (size_t) num_slices + 1];
+		A->sell_slices = num_slices;
+		A->sell_nnz_ext = nnz_ext;
+		A->sell_idx_bytes = idx_count * 2;
+		A->sellw_groups = (int) num_groups;
+		A->sellw_ns = NS;
+		A->sell_split = S;
+		A->sellw_lds = (int) (((long) (max_w + 1) * A->vbytes + 15) / 16 * 16);
+		std::vector<int64_t> gp((size_t) num_groups + 1, 0);
+		for (long g = 0; g < num_groups; g++)
+			gp[(size_t) g + 1] = sdesc[2 * (size_t) std::min<long>(num_slices, (g + 1) * NS)];
+		A->cfg.map = xcd_map_balanced(gp.data(), num_groups, 1, resolve_remap(A->remap, num_groups));
+		A->mem_footprint = (double) (num_slices + 1) * 16 + (double) num_groups * 16 + (double) nnz_ext * A->vbytes + (double) idx_count * 2 + (double) m * 4;
+		return 0;
+	}
 	// ---- windows
 	std::vector<int> grp((size_t) num_groups * 4, 0);
 	long too_wide = 0;
@@ -530,6 +554,7 @@ build_sell_symmetric(spmv_mi355x_matrix * A, const spmv_mi355x_opts & o, const i
 		return 2;
 	A->sell_c = 64;
 	A->sell_delta = false;
+	A->convert_on_device = o.convert_on != 2 && !getenv("SPMV_MI355X_HOST_CONVERT");
 	const int took = build_sell_window(A, rp, ci, va, NS, S, 152 * 1024, true);
 	if (took)
 		return took;

@@ -453,4 +453,227 @@ sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, c
 			mode_counts, nnz_ext_out, idx_bytes_out);
 }
 
+// ---------------------------------------------------------------- the LDS-window layout (build_sell.hip: build_sell_window) on the GPU
+// Same bytes as the host builder (tests/test_gpu_parity.py compares the arrays of the two): 1. window (lowest column, width) of every
+// group of NS slices: one workgroup per group; 2. stable sort of the group's rows by length, descending (the segmented radix sort of
+// the delta conversion, sigma = 64 * NS); 3. slice widths rounded up to whole groups of 4 steps, exclusive scan; 4. one wave per slice
+// writes the values column-major and the 16-bit window-relative indices, 4 steps of a lane side by side.
+
+__global__ __launch_bounds__(CV_BLOCK) void
+window_group_kernel(const int * __restrict__ rp, const int * __restrict__ ci, long m, long sigma, int NS, long num_slices, int sym, int bytes_per_col,
+		long lds_budget_bytes, int * __restrict__ grp, int * __restrict__ flags)
+{
+	__shared__ int s_lo[CV_BLOCK / WAVE], s_hi[CV_BLOCK / WAVE];
+	const long g = blockIdx.x;
+	const long r0 = g * sigma, r1 = r0 + sigma < m ? r0 + sigma : m;
+	int lo = 0x7fffffff, hi = -1;
+	for (long j = (long) rp[r0] + threadIdx.x; j < rp[r1]; j += CV_BLOCK)
+	{
+		lo = min(lo, ci[j]);
+		hi = max(hi, ci[j]);
+	}
+	lo = wave_min_i(lo);
+	hi = wave_max_i(hi);
+	if (threadIdx.x % WAVE == 0)
+	{
+		s_lo[threadIdx.x / WAVE] = lo;
+		s_hi[threadIdx.x / WAVE] = hi;
+	}
+	__syncthreads();
+	if (threadIdx.x != 0)
+		return;
+	for (int w = 1; w < CV_BLOCK / WAVE; w++)
+	{
+		lo = min(lo, s_lo[w]);
+		hi = max(hi, s_hi[w]);
+	}
+	long llo = lo, lhi = hi;
+	if (sym)
+	{
+		llo = llo < r0 ? llo : r0;
+		lhi = lhi > r1 - 1 ? lhi : r1 - 1;
+	}
+	if (lhi < 0)
+		llo = 0;
+	const long w = lhi < 0 ? 1 : lhi - llo + 1;
+	if (w > 65534 || (w + 1) * (long) bytes_per_col > lds_budget_bytes)
+		atomicAdd(&flags[0], 1);
+	const int wi = (int) (w < 0x7fffffffL ? w : 0x7fffffffL);
+	grp[4 * g] = (int) llo;
+	grp[4 * g + 1] = wi;
+	grp[4 * g + 2] = (int) (g * NS);
+	grp[4 * g + 3] = (int) (NS < num_slices - g * NS ? NS : num_slices - g * NS);
+	atomicMax(&flags[1], wi);
+}
+
+__global__ __launch_bounds__(CV_BLOCK) void
+window_width_kernel(const int * __restrict__ rp, const int * __restrict__ row_of_sorted, long num_slices, int64_t * __restrict__ count)
+{
+	const long sl = (long) blockIdx.x * CV_BLOCK + threadIdx.x;
+	if (sl > num_slices)
+		return;
+	int64_t c = 0;
+	if (sl < num_slices)
+	{
+		const int o = row_of_sorted[sl * WAVE];                   // the slice's longest row is its first
+		c = (int64_t) ((rp[o + 1] - rp[o] + 3) / 4 * 4) * WAVE;
+	}
+	count[sl] = c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(CV_BLOCK) void
+window_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, const double * __restrict__ va, const int * __restrict__ row_of_sorted,
+		long m, long num_slices, int NS, int sym, const int * __restrict__ grp, const int64_t * __restrict__ ptr, T * __restrict__ val,
+		unsigned short * __restrict__ idx, int64_t * __restrict__ desc)
+{
+	const long sl = ((long) blockIdx.x * CV_BLOCK + threadIdx.x) / WAVE;
+	const int r = threadIdx.x % WAVE;
+	if (sl > num_slices)
+		return;
+	if (r == 0)
+		desc[2 * sl] = desc[2 * sl + 1] = ptr[sl];
+	if (sl == num_slices)
+		return;
+	const int lo = grp[4 * (sl / NS)], gw = grp[4 * (sl / NS) + 1];
+	const int64_t b = ptr[sl];
+	const long width = (ptr[sl + 1] - b) / WAVE;
+	const long i = sl * WAVE + r;
+	long js = 0, len = 0;
+	if (i < m)
+	{
+		const int o = row_of_sorted[i];
+		js = rp[o];
+		len = rp[o + 1] - js;
+	}
+	const unsigned short pad = (len > 0 && !sym) ? (unsigned short) (ci[js + len - 1] - lo) : (unsigned short) gw;
+	for (long k0 = 0; k0 < width; k0 += 4)
+	{
+		unsigned short q[4];
+		#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const long k = k0 + u;
+			val[b + k * WAVE + r] = k < len ? (T) va[js + k] : (T) 0;
+			q[u] = k < len ? (unsigned short) (ci[js + k] - lo) : pad;
+		}
+		*(uint2 *) (idx + b + k0 * WAVE + r * 4) = make_uint2((unsigned) q[0] | (unsigned) q[1] << 16, (unsigned) q[2] | (unsigned) q[3] << 16);
+	}
+}
+
+// From HOST arrays: upload, convert, drop the uploaded copy. Returns 0 = built (device outputs owned by the caller), 1 = error, 2 = a
+// group's window is too wide (nothing is returned). Host outputs: the slice descriptors (for the tile map and the sizes), the widest window.
+int
+sell_window_convert_device(bool f32, long m, long nnz, int NS, bool sym, long lds_budget_bytes, const int * rp_host, const int * ci_host,
+		const double * va_host, int ** d_grp_out, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned short ** d_idx_out, void ** d_val_out,
+		std::vector<int64_t> & desc_host, int * max_w_out)
+{
+	const long num_slices = (m + WAVE - 1) / WAVE;
+	const long num_groups = (num_slices + NS - 1) / NS;
+	const long sigma = (long) NS * WAVE;
+	const size_t vbytes = f32 ? 4 : 8;
+	if (rp_host[0] != 0)
+	{
+		set_error("sell_window_convert_device: row_ptr must start at 0");
+		return 1;
+	}
+	Scratch tmp, out_guard;
+	int * rp, * ci, * flags;
+	double * va;
+	if (tmp.get(&rp, (size_t) (m + 1) * 4) || tmp.get(&ci, (size_t) nnz * 4) || tmp.get(&va, (size_t) nnz * 8) || tmp.get(&flags, 8))
+		return 1;
+	HIP_TRY(hipMemcpy(rp, rp_host, (size_t) (m + 1) * 4, hipMemcpyHostToDevice));
+	if (nnz)
+	{
+		HIP_TRY(hipMemcpy(ci, ci_host, (size_t) nnz * 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(va, va_host, (size_t) nnz * 8, hipMemcpyHostToDevice));
+	}
+	HIP_TRY(hipMemset(flags, 0, 8));
+	// 1. windows
+	int * grp = nullptr;
+	HIP_TRY(hipMalloc(&grp, ((size_t) std::max<long>(num_groups, 1) * 4 + STREAM_SLACK) * 4));
+	out_guard.ptrs.push_back(grp);
+	HIP_TRY(hipMemset(grp, 0, ((size_t) std::max<long>(num_groups, 1) * 4 + STREAM_SLACK) * 4));
+	if (num_groups > 0)
+	{
+		hipLaunchKernelGGL(window_group_kernel, dim3((unsigned) num_groups), dim3(CV_BLOCK), 0, 0, rp, ci, m, sigma, NS, num_slices, sym ? 1 : 0,
+				(int) (vbytes + (sym ? 8 : 0)), lds_budget_bytes, grp, flags);
+		HIP_TRY(hipGetLastError());
+	}
+	int flags_host[2] = {0, 0};
+	HIP_TRY(hipMemcpy(flags_host, flags, 8, hipMemcpyDeviceToHost));
+	if (flags_host[0])
+		return 2;
+	*max_w_out = flags_host[1];
+	// 2. rows of a group by length, descending, stable
+	int * len, * len_sorted, * ids, * win_off;
+	if (tmp.get(&len, (size_t) m * 4) || tmp.get(&len_sorted, (size_t) m * 4) || tmp.get(&ids, (size_t) m * 4) || tmp.get(&win_off, (size_t) (num_groups + 1) * 4))
+		return 1;
+	int * row_of_sorted = nullptr;
+	HIP_TRY(hipMalloc(&row_of_sorted, ((size_t) std::max<long>(m, 1) + STREAM_SLACK) * 4));
+	out_guard.ptrs.push_back(row_of_sorted);
+	HIP_TRY(hipMemset(row_of_sorted, 0, ((size_t) std::max<long>(m, 1) + STREAM_SLACK) * 4));
+	if (m > 0)
+	{
+		hipLaunchKernelGGL(row_length_kernel, dim3((unsigned) ((m + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0, rp, (int) m, len, ids);
+		hipLaunchKernelGGL(window_offsets_kernel, dim3((unsigned) ((num_groups + 1 + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0, m, sigma, num_groups, win_off);
+		HIP_TRY(hipGetLastError());
+		size_t bytes = 0;
+		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, bytes, len, len_sorted, ids, row_of_sorted, (int) m, (int) num_groups, win_off,
+				win_off + 1, 0, 32, (hipStream_t) 0));
+		void * sort_tmp;
+		if (tmp.get(&sort_tmp, bytes))
+			return 1;
+		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(sort_tmp, bytes, len, len_sorted, ids, row_of_sorted, (int) m, (int) num_groups, win_off,
+				win_off + 1, 0, 32, (hipStream_t) 0));
+	}
+	// 3. slice offsets
+	int64_t * count, * ptr;
+	if (tmp.get(&count, (size_t) (num_slices + 1) * 8) || tmp.get(&ptr, (size_t) (num_slices + 1) * 8))
+		return 1;
+	hipLaunchKernelGGL(window_width_kernel, dim3((unsigned) ((num_slices + 1 + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0, rp, row_of_sorted, num_slices, count);
+	HIP_TRY(hipGetLastError());
+	{
+		size_t bytes = 0;
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, count, ptr, (int) (num_slices + 1), (hipStream_t) 0));
+		void * scan_tmp;
+		if (tmp.get(&scan_tmp, bytes))
+			return 1;
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, bytes, count, ptr, (int) (num_slices + 1), (hipStream_t) 0));
+	}
+	int64_t nnz_ext = 0;
+	HIP_TRY(hipMemcpy(&nnz_ext, ptr + num_slices, 8, hipMemcpyDeviceToHost));
+	// 4. fill
+	void * val = nullptr;
+	unsigned short * idx = nullptr;
+	int64_t * desc = nullptr;
+	const size_t idx_bytes = (size_t) std::max<int64_t>(nnz_ext, 1) * 2;
+	HIP_TRY(hipMalloc(&val, ((size_t) nnz_ext + STREAM_SLACK) * vbytes));
+	out_guard.ptrs.push_back(val);
+	HIP_TRY(hipMalloc(&idx, idx_bytes + 1024));
+	out_guard.ptrs.push_back(idx);
+	HIP_TRY(hipMalloc(&desc, 2 * ((size_t) num_slices + 1) * 8));
+	out_guard.ptrs.push_back(desc);
+	HIP_TRY(hipMemset((char *) val + (size_t) nnz_ext * vbytes, 0, STREAM_SLACK * vbytes));
+	HIP_TRY(hipMemset((char *) idx + (size_t) nnz_ext * 2, 0, idx_bytes + 1024 - (size_t) nnz_ext * 2));
+	const unsigned slice_grid = (unsigned) (((num_slices + 1) * WAVE + CV_BLOCK - 1) / CV_BLOCK);
+	if (f32)
+		hipLaunchKernelGGL((window_fill_kernel<float>), dim3(slice_grid), dim3(CV_BLOCK), 0, 0, rp, ci, va, row_of_sorted, m, num_slices, NS, sym ? 1 : 0, grp, ptr,
+				(float *) val, idx, desc);
+	else
+		hipLaunchKernelGGL((window_fill_kernel<double>), dim3(slice_grid), dim3(CV_BLOCK), 0, 0, rp, ci, va, row_of_sorted, m, num_slices, NS, sym ? 1 : 0, grp, ptr,
+				(double *) val, idx, desc);
+	HIP_TRY(hipGetLastError());
+	desc_host.assign(2 * ((size_t) num_slices + 1), 0);
+	HIP_TRY(hipMemcpy(desc_host.data(), desc, desc_host.size() * 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipDeviceSynchronize());
+	out_guard.ptrs.clear();                            // success: ownership moves to the caller
+	*d_grp_out = grp;
+	*d_row_of_sorted_out = row_of_sorted;
+	*d_desc_out = desc;
+	*d_idx_out = idx;
+	*d_val_out = val;
+	return 0;
+}
+
 }  // namespace spmv

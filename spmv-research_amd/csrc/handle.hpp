@@ -52,7 +52,7 @@ struct spmv_mi355x_matrix {
 	int * d_coob_long_row = nullptr;       // [num_long] their global row numbers
 	void * d_coob_carry = nullptr;         // [num_long][32] partial sums of the split rows
 	int coob_ranges = 0, coob_chunk_rows = 0, coob_lds = 0, coob_num_long = 0;
-	long coob_batches = 0;
+	long coob_batches = 0, coob_chunks = 0;
 	// SELL
 	int sell_c = 0;
 	long sell_sigma = 0, sell_slices = 0, sell_nnz_ext = 0;
@@ -77,7 +77,7 @@ struct spmv_mi355x_matrix {
 	void * d_x = nullptr;
 	void * d_y = nullptr;
 	int placement_level = 0;               // opts.placement: 0 / 2 = off, 1 = the device's vector pools, 3 = + search over the matrix arrays
-	long placement_budget_gib = 0;         // transient ballast the one walk of a device may hold (0 = 96)
+	long placement_budget_gib = 0;         // transient ballast the one walk of a device may hold (0 = 160)
 	const void * cached_x_host = nullptr;
 	bool y_downloaded = false;
 	bool always_copy = false;

@@ -223,11 +223,24 @@ sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * 
 	}
 	if (NSTEPS == 4)
 	{
+#if defined(SELL_ABL) && SELL_ABL == 2
+		const T v0 = 1, v1 = 1, v2 = 1, v3 = 1;
+#elif defined(SELL_ABL) && SELL_ABL == 3
+		typedef T T2 __attribute__((ext_vector_type(2)));
+		const T2 w0 = ld_stream<NT>(reinterpret_cast<const T2 *>(vp - lane) + lane);
+		const T2 w1 = ld_stream<NT>(reinterpret_cast<const T2 *>(vp - lane + 2 * WAVE) + lane);
+		const T v0 = w0.x, v1 = w0.y, v2 = w1.x, v3 = w1.y;
+#else
 		const T v0 = ld_stream<NT>(vp);
 		const T v1 = ld_stream<NT>(vp + WAVE);
 		const T v2 = ld_stream<NT>(vp + 2 * WAVE);
 		const T v3 = ld_stream<NT>(vp + 3 * WAVE);
+#endif
+#if defined(SELL_ABL) && SELL_ABL == 1
+		const T x0 = (T) c0, x1 = (T) c1, x2 = (T) c2, x3 = (T) c3;
+#else
 		const T x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+#endif
 		s = fma_t<T>(v0, x0, s);
 		s = fma_t<T>(v1, x1, s);
 		s = fma_t<T>(v2, x2, s);

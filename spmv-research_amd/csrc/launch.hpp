@@ -97,6 +97,15 @@ int sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigm
 int sell_delta_convert_resident(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp, const int * ci,
 		const double * va, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
 		std::vector<int64_t> & val_ptr_host, long mode_counts[4], int64_t * nnz_ext_out, int64_t * idx_bytes_out);
+// the entry arrays of the column-blocked layout on the GPU (convert_coo.hip)
+int blocked_entries_convert_device(bool f32, bool uniform, long m, long nnz, const int * rp_host, const int * ci_host, const double * va_host, long NR, int WGS, long CH,
+		const std::vector<int> & range_row, const std::vector<int> & range_long, const std::vector<int> & long_row, const std::vector<int> & chunk_ptr,
+		const std::vector<int> & chunk_row, const std::vector<int> & wg_rows, long SPAN, long BATCH, int slot_bits, int SPARE, long ghost_batches,
+		std::vector<int> & batch_ptr, unsigned ** d_ent_out, void ** d_val_out, int ** d_batch_base_out);
+// CSR -> the LDS-window layout on the GPU (convert_sell.hip); 0 = built, 1 = error, 2 = a group's window is too wide
+int sell_window_convert_device(bool f32, long m, long nnz, int NS, bool sym, long lds_budget_bytes, const int * rp_host, const int * ci_host,
+		const double * va_host, int ** d_grp_out, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned short ** d_idx_out, void ** d_val_out,
+		std::vector<int64_t> & desc_host, int * max_w_out);
 
 // ---- COO (kernels_coo.hip)
 int coo_wave_items(int items_per_lane);                                // entries per wavefront

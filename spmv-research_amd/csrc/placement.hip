@@ -10,11 +10,13 @@
 //
 // Round 2 searched per handle (ten sites, ~165 GiB of ballast, ~600 launches, every handle again). Round 3: ONE walk per process and
 // device, made by the first handle that asks (opts.placement = 1 or SPMV_MI355X_PLACEMENT >= 1; OFF by default): candidates for y
-// are taken from deeper and deeper in the driver's pool, 16 GiB of ballast apart, until one runs the handle's kernel 4 % faster or
-// slower than the first — those two candidates are in blocks of different class and are KEPT as the device's two vector pools
-// (1-4 GiB each), the ballast (at most opts.placement_budget_gib, default 96, never the last 8 GiB of the device) goes back. From
-// then on a vector of any handle of the process is a slice of one of the pools: two trials (6 launches each) decide which. A
-// scope guard returns ballast and rejected candidates on every way out. Other processes on the same GPU: the walk's free-memory
+// are taken from deeper and deeper in the driver's pool, 16 GiB of ballast apart; a candidate under which the handle's kernel runs
+// 1.5 % faster or slower than under every candidate kept so far is in a block of another class and is KEPT as one more of the device's
+// vector pools (1-4 GiB each, at most four). The walk ends three candidates after the last new class once it has two (boxes differ:
+// the second class turned up 16 GiB in on some, 128 GiB in on others — profiles/r03_placement_walk.txt — and some show a third), or
+// at opts.placement_budget_gib of ballast (default 160, never the last 8 GiB of the device); the ballast goes back. From then on a
+// vector of any handle of the process is a slice of one of the pools: one trial per pool (6 launches each) decides which. A scope
+// guard returns ballast and rejected candidates on every way out. Other processes on the same GPU: the walk's free-memory
 // check (hipMemGetInfo, then hipMalloc) is racy between processes, and a neighbour's kernels run a few % slower for the seconds
 // the driver takes to clear the returned ballast — one more reason why this is opt-in.
 // Level 3 (SPMV_MI355X_PLACEMENT=3 / opts.placement = 3) adds round 2's search over the handle's matrix arrays (worth 1-2 %).
@@ -34,8 +36,10 @@ constexpr size_t PLACE_MIN_BYTES = (size_t) 8 << 20;       // smaller problems r
 constexpr size_t WALK_STEP = (size_t) 16 << 30;            // blocks are 32 GiB: two candidates per block
 constexpr size_t KEEP_FREE = (size_t) 8 << 30;             // never take the last of the device for ballast
 constexpr size_t POOL_ALIGN = (size_t) 2 << 20;
-constexpr double CONTRAST = 1.04;                          // classes differ by 12-15 % (the two fast ones by 3 %), repeats by < 0.3 %
+constexpr double CONTRAST = 1.015;                         // classes differ by 12-15 % (the two fast ones by 2-3 %), repeats by < 0.3 %
 constexpr int MAX_DEV = 64;
+constexpr int MAX_POOLS = 4;
+constexpr int WALK_ON = 3;                                 // candidates tried after the last new class before the walk ends
 
 // SPMV_MI355X_PLACEMENT: unset = what the handle's opts say; 0 = off; 1 = pools; 2 = pools + log; 3 = + search over the matrix arrays;
 // 4 = 3 + the (value array block) x (y block) table of profiles/r02_placement.md §4
@@ -80,8 +84,12 @@ struct Pool {
 };
 
 struct DevPools {
-	int state = 0;                 // 0 = no walk yet, 1 = two pools of different class, 2 = walked: no contrast seen (plain allocations)
-	Pool pool[2];
+	int state = 0;                 // 0 = no walk yet, 1 = pools of different class, 2 = walked: no contrast seen (plain allocations)
+	int npools = 0;
+	Pool pool[MAX_POOLS];
+	double walk_us[MAX_POOLS] = {0, 0, 0, 0};   // the walking handle's kernel with y in pool k
+	long walked_gib = 0;           // ballast the walk held at its deepest
+	int candidates = 0;
 };
 
 DevPools g_dev[MAX_DEV];
@@ -148,7 +156,7 @@ kernel_us(spmv_mi355x_matrix * A, const void * x, void * y)
 size_t
 budget_bytes(const spmv_mi355x_matrix * A)
 {
-	long gib = A->placement_budget_gib > 0 ? A->placement_budget_gib : 96;
+	long gib = A->placement_budget_gib > 0 ? A->placement_budget_gib : 160;
 	if (const char * e = getenv("SPMV_MI355X_PLACEMENT_BUDGET_GIB"))
 		if (atol(e) > 0)
 			gib = atol(e);
@@ -179,10 +187,10 @@ build_pools(spmv_mi355x_matrix * A, DevPools & dp)
 		return 1;
 	if (t0 < 20.0)                                 // launch-bound: differences between blocks drown in the noise
 		return 0;
-	void * other = nullptr;
-	double t_other = 0;
-	int tries = 1;
-	for (size_t walked = 0; walked + WALK_STEP <= budget && !other; walked += WALK_STEP)
+	void * kept[MAX_POOLS] = {cand0, nullptr, nullptr, nullptr};
+	double t_kept[MAX_POOLS] = {t0, 0, 0, 0};
+	int nk = 1, tries = 1, since_new = 0;
+	for (size_t walked = 0; walked + WALK_STEP <= budget && nk < MAX_POOLS && !(nk >= 2 && since_new >= WALK_ON); walked += WALK_STEP)
 	{
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < WALK_STEP + pool_bytes + KEEP_FREE)
@@ -206,37 +214,56 @@ build_pools(spmv_mi355x_matrix * A, DevPools & dp)
 		tries++;
 		if (t < 0)
 			return 1;
+		bool fresh = true;
+		for (int k = 0; k < nk; k++)
+			fresh = fresh && (t * CONTRAST < t_kept[k] || t > t_kept[k] * CONTRAST);
 		if (verbose())
-			fprintf(stderr, "[spmv_mi355x] placement walk: %.0f GiB in, %.1f us per SpMV (first candidate %.1f us)\n", (double) (walked + WALK_STEP) / (1 << 30), t, t0);
-		if (t * CONTRAST < t0 || t > t0 * CONTRAST)
+			fprintf(stderr, "[spmv_mi355x] placement walk: %.0f GiB in, %.1f us per SpMV%s\n", (double) (walked + WALK_STEP) / (1 << 30), t, fresh ? " (a new class: kept)" : "");
+		since_new++;
+		if (fresh)
 		{
-			other = cand;
-			t_other = t;
+			kept[nk] = cand;
+			t_kept[nk++] = t;
+			since_new = 0;
 		}
 	}
-	if (other)
+	dp.candidates = tries;
+	dp.walked_gib = (long) ((size_t) (tries - 1) * (WALK_STEP >> 30));
+	if (nk >= 2)
 	{
-		// keep the two: take them out of the guard's hands
+		// keep them: take them out of the guard's hands
 		for (void *& p : held.v)
-			if (p == cand0 || p == other)
-				p = nullptr;
-		dp.pool[0].base = (char *) cand0;
-		dp.pool[1].base = (char *) other;
-		for (Pool & p : dp.pool)
+			for (int k = 0; k < nk; k++)
+				if (p && p == kept[k])
+					p = nullptr;
+		dp.npools = nk;
+		for (int k = 0; k < nk; k++)
 		{
+			Pool & p = dp.pool[k];
+			p.base = (char *) kept[k];
 			p.size = pool_bytes;
 			p.free_list.assign(1, std::make_pair((size_t) 0, pool_bytes));
 			p.live.clear();
+			dp.walk_us[k] = t_kept[k];
 		}
 		dp.state = 1;
 	}
+	else
+		dp.walk_us[0] = t0;
 	held.release();
 	if (verbose())
+	{
 		fprintf(stderr, "[spmv_mi355x] placement: device %d, %d candidate(s), %s, pools of %.0f MiB, %.0f ms\n", A->device, tries,
-				other ? "two block classes found" : "no contrast inside the budget: plain allocations", (double) pool_bytes / (1 << 20),
+				nk >= 2 ? "block classes found" : "no contrast inside the budget: plain allocations", (double) pool_bytes / (1 << 20),
 				std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e3);
-	if (other && verbose())
-		fprintf(stderr, "[spmv_mi355x] placement: y in pool 0: %.1f us, in pool 1: %.1f us per SpMV of %s\n", t0, t_other, A->format_name);
+		if (nk >= 2)
+		{
+			fprintf(stderr, "[spmv_mi355x] placement: us per SpMV of %s with y in pool 0..%d:", A->format_name, nk - 1);
+			for (int k = 0; k < nk; k++)
+				fprintf(stderr, " %.1f", t_kept[k]);
+			fprintf(stderr, "\n");
+		}
+	}
 	return 0;
 }
 
@@ -293,8 +320,9 @@ placement_map(spmv_mi355x_matrix * A)
 // where the handle's kernel ran fastest, if that beats where it was by 2 %. Sites that end up unused, the ballast between them and the
 // originals of moved arrays are returned — by the guard on every way out.
 int
-search_arrays(spmv_mi355x_matrix * A)
+search_arrays(spmv_mi355x_matrix * A, const void * x, void * y, bool * moved_out)
 {
+	*moved_out = false;
 	const auto c0 = std::chrono::steady_clock::now();
 	struct Slot { void ** p; const char * name; size_t size; };
 	Slot all[] = {{&A->d_val, "val", 0}, {(void **) &A->d_sell_idx, "sell_idx", 0}, {(void **) &A->d_col, "col", 0},
@@ -352,7 +380,7 @@ search_arrays(spmv_mi355x_matrix * A)
 			break;
 		sites.push_back(bufs);
 	}
-	double t_cur = kernel_us(A, A->d_x, A->d_y);
+	double t_cur = kernel_us(A, x, y);
 	const double t_start = t_cur;
 	if (t_cur < 0)
 		return 1;
@@ -383,18 +411,20 @@ search_arrays(spmv_mi355x_matrix * A)
 					return 1;
 				}
 				*sl->p = dst;
-				const double t = kernel_us(A, A->d_x, A->d_y);
+				const double t = kernel_us(A, x, y);
 				*sl->p = orig;
 				if (t < 0)
 					return 1;
 				if (verbose())
 					fprintf(stderr, " %.0f", t);
-				if (t < t_best * 0.98)
+				if (t < t_best)
 				{
 					best = (int) s;
 					t_best = t;
 				}
 			}
+			if (best >= 0 && t_best >= t_cur * 0.98)
+				best = -1;                                 // the fastest site is not worth a move
 			if (best >= 0)
 			{
 				// the array moves in: the site buffer leaves the guard, the old home enters it
@@ -405,6 +435,7 @@ search_arrays(spmv_mi355x_matrix * A)
 				*sl->p = now;
 				t_cur = t_best;
 				moved_any = 1;
+				*moved_out = true;
 			}
 			if (verbose())
 				fprintf(stderr, " -> %s, %.1f us\n", best >= 0 ? "moved" : "stays", t_cur);
@@ -440,25 +471,32 @@ place_vector(spmv_mi355x_matrix * A, void ** out, size_t bytes, bool is_output)
 	}
 	if (dp.state != 1)
 		return plain_alloc(out, bytes);
-	void * c[2] = {pool_alloc(dp.pool[0], bytes), pool_alloc(dp.pool[1], bytes)};
-	if (!c[0] || !c[1])
+	void * c[MAX_POOLS] = {nullptr, nullptr, nullptr, nullptr};
+	bool room = true;
+	for (int k = 0; k < dp.npools; k++)
+		room = (c[k] = pool_alloc(dp.pool[k], bytes)) != nullptr && room;
+	if (!room)
 	{
-		for (int k = 0; k < 2; k++)
+		for (int k = 0; k < dp.npools; k++)
 			if (c[k])
 				pool_free(dp.pool[k], c[k]);
 		return plain_alloc(out, bytes);                // pools exhausted
 	}
-	double t[2];
-	for (int k = 0; k < 2; k++)
+	double t[MAX_POOLS] = {0, 0, 0, 0};
+	int win = 0;
+	for (int k = 0; k < dp.npools; k++)
 	{
 		HIP_TRY(hipMemsetAsync(c[k], 0, bytes, A->stream));
 		HIP_TRY(hipStreamSynchronize(A->stream));
 		t[k] = is_output ? kernel_us(A, A->d_x, c[k]) : kernel_us(A, c[k], A->d_y);
 		if (t[k] < 0)
 			return 1;
+		if (t[k] < t[win])
+			win = k;
 	}
-	const int win = t[1] < t[0] ? 1 : 0;
-	pool_free(dp.pool[1 - win], c[1 - win]);
+	for (int k = 0; k < dp.npools; k++)
+		if (k != win)
+			pool_free(dp.pool[k], c[k]);
 	if (is_output)
 	{
 		HIP_TRY(hipMemsetAsync(c[win], 0, bytes, A->stream));      // the trials wrote into it
@@ -466,8 +504,13 @@ place_vector(spmv_mi355x_matrix * A, void ** out, size_t bytes, bool is_output)
 	}
 	*out = c[win];
 	if (verbose())
-		fprintf(stderr, "[spmv_mi355x] placed %s of %s (%.0f MiB): %.1f / %.1f us per SpMV in pool 0 / 1 -> pool %d\n", is_output ? "an output vector" : "an input vector",
-				A->format_name, (double) bytes / (1 << 20), t[0], t[1], win);
+	{
+		fprintf(stderr, "[spmv_mi355x] placed %s of %s (%.0f MiB): us per SpMV in pool 0..%d:", is_output ? "an output vector" : "an input vector", A->format_name,
+				(double) bytes / (1 << 20), dp.npools - 1);
+		for (int k = 0; k < dp.npools; k++)
+			fprintf(stderr, " %.1f", t[k]);
+		fprintf(stderr, " -> pool %d\n", win);
+	}
 	return 0;
 }
 
@@ -489,7 +532,40 @@ vector_free(void * p)
 	return 0;
 }
 
-// Once per handle, when its own x / y pair is first needed (A->d_x exists as a plain, zeroed allocation): y into the better pool, then x.
+// is p a slice of one of the device's pools?
+static bool
+in_pools(const spmv_mi355x_matrix * A, const void * p)
+{
+	std::lock_guard<std::mutex> lock(g_mu);
+	const DevPools & dp = g_dev[std::min(std::max(A->device, 0), MAX_DEV - 1)];
+	bool pooled = false;
+	for (const Pool & pl : dp.pool)
+		pooled = pooled || (dp.state == 1 && pl.base && (const char *) p >= pl.base && (const char *) p < pl.base + pl.size);
+	return pooled;
+}
+
+// x (zero-filled, not yet written by the caller) into the pool where A's kernel reads it fastest; stays where it is when there are no pools
+static int
+place_own_x(spmv_mi355x_matrix * A)
+{
+	void * x2 = nullptr;
+	const size_t xb = (size_t) std::max<long>(A->n, 1) * A->vbytes;
+	if (place_vector(A, &x2, xb, false))
+		return 1;
+	// x2 is a pool slice only when the pools exist and x is large enough; otherwise it is one more plain allocation: keep the first
+	if (in_pools(A, x2))
+	{
+		if (vector_free(A->d_x))
+			return 1;
+		A->d_x = x2;
+		return 0;
+	}
+	return vector_free(x2);
+}
+
+// Once per handle, when its own x / y pair is first needed (A->d_x exists as a plain, zeroed allocation): y into the best pool, then x;
+// level 3: then the matrix arrays, and when one of them moved, y and x once more (the best block for a vector is one of another class
+// than the value array's: profiles/r03_placement_walk.txt).
 int
 tune_placement(spmv_mi355x_matrix * A)
 {
@@ -497,27 +573,23 @@ tune_placement(spmv_mi355x_matrix * A)
 		return 1;
 	if (level_of(A) < 1)
 		return 0;
-	void * x2 = nullptr;
-	const size_t xb = (size_t) std::max<long>(A->n, 1) * A->vbytes;
-	if (place_vector(A, &x2, xb, false))
+	if (place_own_x(A))
 		return 1;
-	// x2 is a pool slice only when the pools exist and x is large enough; otherwise it is one more plain allocation: keep the first
-	bool pooled = false;
+	if (level_of(A) >= 3)
 	{
-		std::lock_guard<std::mutex> lock(g_mu);
-		const DevPools & dp = g_dev[std::min(std::max(A->device, 0), MAX_DEV - 1)];
-		for (const Pool & pl : dp.pool)
-			pooled = pooled || (dp.state == 1 && pl.base && (char *) x2 >= pl.base && (char *) x2 < pl.base + pl.size);
+		bool moved = false;
+		if (search_arrays(A, A->d_x, A->d_y, &moved))
+			return 1;
+		if (moved && in_pools(A, A->d_y))
+		{
+			void * y2 = nullptr;
+			if (place_vector(A, &y2, (size_t) (A->m + 64) * A->vbytes, true) || vector_free(A->d_y))
+				return 1;
+			A->d_y = y2;
+			if (place_own_x(A))
+				return 1;
+		}
 	}
-	if (pooled)
-	{
-		(void) hipFree(A->d_x);
-		A->d_x = x2;
-	}
-	else if (vector_free(x2))
-		return 1;
-	if (level_of(A) >= 3 && search_arrays(A))
-		return 1;
 	if (level_of(A) >= 4)
 		return placement_map(A);
 	return 0;
@@ -556,9 +628,43 @@ spmv_mi355x_input_alloc(spmv_mi355x_matrix * A, size_t bytes, void ** out)
 }
 
 int
+spmv_mi355x_place_arrays(spmv_mi355x_matrix * A, const void * x_dev, void * y_dev)
+{
+	if (!A || !x_dev || !y_dev)
+	{
+		spmv::set_error("place_arrays: NULL argument");
+		return 1;
+	}
+	if (spmv::ensure_x(A))                   // sets the device, creates the stream the trials run on
+		return 1;
+	bool moved = false;
+	return spmv::search_arrays(A, x_dev, y_dev, &moved);
+}
+
+int
 spmv_mi355x_output_free(void * p)
 {
 	return spmv::vector_free(p);
+}
+
+int
+spmv_mi355x_placement_info(int device, int * state_out, int * candidates_out, long * walked_gib_out, int * pools_out, double us_out[4])
+{
+	if (device < 0 || device >= spmv::MAX_DEV)
+	{
+		spmv::set_error("placement_info: device %d", device);
+		return 1;
+	}
+	std::lock_guard<std::mutex> lock(spmv::g_mu);
+	const spmv::DevPools & dp = spmv::g_dev[device];
+	if (state_out) *state_out = dp.state;
+	if (candidates_out) *candidates_out = dp.candidates;
+	if (walked_gib_out) *walked_gib_out = dp.walked_gib;
+	if (pools_out) *pools_out = dp.npools;
+	if (us_out)
+		for (int k = 0; k < spmv::MAX_POOLS; k++)
+			us_out[k] = dp.walk_us[k];
+	return 0;
 }
 
 int
@@ -575,9 +681,12 @@ spmv_mi355x_placement_release(int device)
 			dp.state = 0;
 			continue;
 		}
-		if (!dp.pool[0].live.empty() || !dp.pool[1].live.empty())
+		size_t live = 0;
+		for (const spmv::Pool & pl : dp.pool)
+			live += pl.live.size();
+		if (live)
 		{
-			spmv::set_error("placement_release: device %d still has %zu vector(s) in its pools", d, dp.pool[0].live.size() + dp.pool[1].live.size());
+			spmv::set_error("placement_release: device %d still has %zu vector(s) in its pools", d, live);
 			return 1;
 		}
 		int cur = -1;
@@ -590,6 +699,7 @@ spmv_mi355x_placement_release(int device)
 		}
 		if (cur >= 0)
 			(void) hipSetDevice(cur);
+		dp.npools = 0;
 		dp.state = 0;
 	}
 	return 0;

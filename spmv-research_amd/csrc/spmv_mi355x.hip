@@ -28,6 +28,7 @@ init_handle(spmv_mi355x_matrix * A, int format, int precision, int device, const
 	A->device = device;
 	A->placement_level = (o.placement == 1 || o.placement == 3 || o.placement == 4) ? o.placement : 0;      // 0 and 2: off
 	A->placement_budget_gib = o.placement_budget_gib > 0 ? o.placement_budget_gib : 0;
+	A->convert_on_device = o.convert_on != 2 && !getenv("SPMV_MI355X_HOST_CONVERT");      // layouts with a GPU builder: SELL delta, SELL window, column-blocked
 	A->n = n;
 	A->m = m;
 	A->nnz = nnz;
@@ -447,6 +448,63 @@ spmv_mi355x_spmv(spmv_mi355x_matrix * A, const void * x_host, void * y_host)
 		if (spmv_mi355x_download_y(A, y_host))
 			return 1;
 	return 0;
+}
+
+// One of the handle's stored arrays as it lies in device memory, copied to a malloc'ed host buffer (free with spmv_mi355x_free): the
+// LDS-window SELL layout and the column-blocked layout, whose host and GPU builders must give the same bytes (tests/test_gpu_parity.py).
+int
+spmv_mi355x_stored_array(const spmv_mi355x_matrix * A, const char * name, void ** out, size_t * bytes_out)
+{
+	if (!A || !name || !out || !bytes_out)
+	{
+		set_error("stored_array: NULL argument");
+		return 1;
+	}
+	*out = nullptr;
+	*bytes_out = 0;
+	struct Arr { const char * name; const void * p; size_t bytes; };
+	std::vector<Arr> arrs;
+	if (A->format == SPMV_MI355X_SELL_C_SIGMA && A->sell_window)
+		arrs = {{"val", A->d_val, (size_t) A->sell_nnz_ext * A->vbytes}, {"idx", A->d_sell_idx, (size_t) A->sell_idx_bytes},
+		        {"desc", A->d_sell_desc, 2 * ((size_t) A->sell_slices + 1) * 8}, {"row_of_sorted", A->d_row_of_sorted, (size_t) A->m * 4},
+		        {"groups", A->d_sellw_grp, (size_t) A->sellw_groups * 16}};
+	else if (A->d_coob_ent)
+	{
+		const size_t NT = (size_t) A->coob_ranges * spmv::coo_blocked_wgs_per_range(), BATCH = (size_t) spmv::coo_blocked_batch_entries(A->cfg.unit != 0);
+		const size_t stored = ((size_t) A->coob_batches + 2) * BATCH;
+		arrs = {{"entries", A->d_coob_ent, stored * 4}, {"val", A->d_val, A->cfg.unit ? 0 : stored * A->vbytes},
+		        {"batch_base", A->d_coob_batch_base, stored / 64 * 4}, {"batch_ptr", A->d_coob_batch_ptr, (NT + 1) * 4},
+		        {"chunk_ptr", A->d_coob_chunk_ptr, (NT + 1) * 4}, {"chunk_row", A->d_coob_chunk_row, (size_t) A->coob_chunks * 4},
+		        {"wg_rows", A->d_coob_wg_rows, NT * 4}, {"range_row", A->d_coob_range_row, ((size_t) A->coob_ranges + 1) * 4},
+		        {"range_long", A->d_coob_range_long, ((size_t) A->coob_ranges + 1) * 4}, {"long_row", A->d_coob_long_row, (size_t) A->coob_num_long * 4}};
+	}
+	else
+	{
+		set_error("stored_array: only for the LDS-window SELL layout and the column-blocked layout (this handle: %s)", A->format_name);
+		return 1;
+	}
+	for (const Arr & a : arrs)
+		if (!strcmp(a.name, name))
+		{
+			HIP_TRY(hipSetDevice(A->device));
+			void * host = malloc(std::max<size_t>(a.bytes, 1));
+			if (!host)
+			{
+				set_error("stored_array: out of host memory (%zu bytes)", a.bytes);
+				return 1;
+			}
+			if (a.bytes && hipMemcpy(host, a.p, a.bytes, hipMemcpyDeviceToHost) != hipSuccess)
+			{
+				free(host);
+				set_error("stored_array: copy failed: %s", hipGetErrorString(hipGetLastError()));
+				return 1;
+			}
+			*out = host;
+			*bytes_out = a.bytes;
+			return 0;
+		}
+	set_error("stored_array: %s has no array '%s'", A->format_name, name);
+	return 1;
 }
 
 int

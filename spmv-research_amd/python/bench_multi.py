@@ -263,6 +263,8 @@ class RowsVariant:
         self.y = self.y_vec.torch()
         self.x_vec = self.mats[0].input_vector(self.n_x)        # ... and x the same way (a zero-copy torch view: the collectives write into it)
         self.x_full = self.x_vec.torch()
+        if c.opts.get("placement") == 3:
+            self.mats[0].place_arrays(self.x_vec.ptr, self.y_vec.ptr)          # ... and the local part's matrix arrays relative to the two
         self.y.fill_(1.0)
         self.x_loc = self.x_full[c.rank * self.padded:(c.rank + 1) * self.padded]       # in-place allgather: own slice lives inside x_full
         self._fill_own()
@@ -618,7 +620,8 @@ def run(args, B):
     c.t_dtype = torch.float64 if c.dts == "f64" else torch.float32
     c.vbytes = 8 if c.dts == "f64" else 4
     c.opts = B.collect_opts(args, workload)
-    c.opts.setdefault("placement", 1)        # vectors from the engine's pools (csrc/placement.hip): opt-in, and the bench opts in
+    c.opts.setdefault("placement", getattr(c.args, "placement", 3))        # csrc/placement.hip: opt-in, and the bench opts in (bench.py --placement)
+    c.opts.setdefault("placement_budget_gib", 160)
     c.sp = torch.cuda.current_stream().cuda_stream
     t0 = time.time()
     c.src = Source(H, B, workload, args.scale)

@@ -37,7 +37,7 @@ SYMBOLS = [
     "spmv_mi355x_destroy", "spmv_mi355x_format_name", "spmv_mi355x_mem_footprint", "spmv_mi355x_csr_mem_footprint",
     "spmv_mi355x_rows", "spmv_mi355x_cols", "spmv_mi355x_nnz", "spmv_mi355x_spmv", "spmv_mi355x_set_always_copy",
     "spmv_mi355x_upload_x", "spmv_mi355x_download_y", "spmv_mi355x_spmv_device_async", "spmv_mi355x_time_device",
-    "spmv_mi355x_kernel_info", "spmv_mi355x_x_device", "spmv_mi355x_y_device", "spmv_mi355x_sell_layout",
+    "spmv_mi355x_kernel_info", "spmv_mi355x_x_device", "spmv_mi355x_y_device", "spmv_mi355x_sell_layout", "spmv_mi355x_stored_array",
     "spmv_mi355x_merge_tiles", "spmv_mi355x_free", "spmv_mi355x_precision", "spmv_mi355x_device",
     "spmv_mi355x_pcg", "spmv_mi355x_pbicgstab", "spmv_mi355x_pcg_dist", "spmv_mi355x_pbicgstab_dist",
     "spmv_mi355x_copy_device_async",
@@ -45,7 +45,7 @@ SYMBOLS = [
     "spmv_mi355x_partitioned_set_always_copy", "spmv_mi355x_time_partitioned", "spmv_mi355x_partitioned_parts",
     "spmv_mi355x_partitioned_offsets", "spmv_mi355x_partitioned_format_name", "spmv_mi355x_partitioned_exchange",
     "spmv_mi355x_partitioned_mem_footprint",
-    "spmv_mi355x_upload_y", "spmv_mi355x_output_alloc", "spmv_mi355x_input_alloc", "spmv_mi355x_output_free", "spmv_mi355x_placement_release",
+    "spmv_mi355x_upload_y", "spmv_mi355x_output_alloc", "spmv_mi355x_input_alloc", "spmv_mi355x_output_free", "spmv_mi355x_placement_release", "spmv_mi355x_placement_info", "spmv_mi355x_place_arrays",
     "spmv_mi355x_csr_stream_begin", "spmv_mi355x_csr_stream_append", "spmv_mi355x_create_from_stream", "spmv_mi355x_csr_stream_discard",
 ]
 
@@ -92,6 +92,14 @@ def _check(rc):
 def placement_release(device=-1):
     """Free the vector pools of a device (-1: all) — no vector of them may be live (include/spmv_mi355x.h)."""
     _check(lib().spmv_mi355x_placement_release(C.c_int(device)))
+
+
+def placement_info(device=0):
+    """What the one walk of a device found (include/spmv_mi355x.h): dict(state, candidates, walked_gib, pools, us_per_pool)."""
+    st, cand, gib, npool, us = C.c_int(), C.c_int(), C.c_long(), C.c_int(), (C.c_double * 4)()
+    _check(lib().spmv_mi355x_placement_info(C.c_int(device), C.byref(st), C.byref(cand), C.byref(gib), C.byref(npool), us))
+    return dict(state={0: "no walk", 1: "pools kept", 2: "no contrast: plain allocations"}[st.value], candidates=cand.value, walked_gib=gib.value,
+                pools=npool.value, us_per_pool=[round(us[k], 1) for k in range(npool.value)])
 
 
 def device_count():
@@ -402,6 +410,18 @@ class Matrix:
         for p in (sp, col, val, ros):
             lib().spmv_mi355x_free(p)
         return out
+
+    def place_arrays(self, x_ptr, y_ptr):
+        """The search over the handle's matrix arrays (opts.placement = 3) for a caller's device vectors; y is overwritten."""
+        _check(lib().spmv_mi355x_place_arrays(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def stored_array(self, name, dtype=np.uint8):
+        """One stored array of the LDS-window SELL / column-blocked layout as it lies in device memory (include/spmv_mi355x.h)."""
+        out, nb = C.c_void_p(), C.c_size_t()
+        _check(lib().spmv_mi355x_stored_array(self.h, name.encode(), C.byref(out), C.byref(nb)))
+        a = np.frombuffer(C.string_at(out.value, nb.value), dtype=np.uint8).copy().view(dtype) if nb.value else np.zeros(0, dtype)
+        lib().spmv_mi355x_free(out)
+        return a
 
     def merge_tiles(self):
         nt, ti = C.c_long(), C.c_long()

@@ -254,6 +254,40 @@ def test_blocked_layout_with_several_passes_and_split_rows(eng, oracle, fmt, mon
                 A.close()
 
 
+BLOCKED_ARRAYS = ("entries", "val", "batch_base", "batch_ptr", "chunk_ptr", "chunk_row", "wg_rows", "range_row", "range_long", "long_row")
+
+
+@pytest.mark.parametrize("small_lds", [False, True])
+def test_device_blocked_builder_equals_host_builder(eng, oracle, monkeypatch, small_lds):
+    """The entry arrays of the column-blocked layout (kernels_coo.hip) built on the GPU (convert_coo.hip: keys, one stable radix sort, a
+    wave per workgroup cutting the sorted entries into groups) hold the same bytes as the host builder's (build_coo.hip), in every
+    stored array: power-law, split rows, several passes, pattern (unit) values, a column-block width, empty rows, one huge row."""
+    if small_lds:
+        monkeypatch.setenv("SPMV_MI355X_COOB_ROWS", "64")
+        monkeypatch.setenv("SPMV_MI355X_COOB_LONG_MIN", "8")
+    rng = np.random.default_rng(12)
+    cases = [load_case(c)[1] for c in ("huge_row", "empty_rows_formats", "rectangular", "pattern_general")]
+    cases = [(g["row_ptr"], g["col_idx"], g["values"], len(g["row_ptr"]) - 1, len(g["x_rand"])) for g in cases]
+    rp, ci, a = synth(rng, 70000, 70000, "powerlaw")
+    cases.append((rp, ci, a, 70000, 70000))
+    cases.append((rp, ci, np.ones_like(a), 70000, 70000))                      # unit values: no value array, 8 entries per lane and batch
+    rp, ci, a = synth(rng, 3000, 200000, "one_row")
+    cases.append((rp, ci, a, 3000, 200000))
+    for rp, ci, a, m, n in cases:
+        x = rng.uniform(-1, 1, n)
+        for fmt, dtype, cb in (("coo", np.float64, -1), ("csr_merge", np.float32, -1), ("coo", np.float32, 7)):
+            H = eng.Matrix(rp, ci, a, m, n, fmt, dtype, col_blocks=cb, convert_on=2)
+            D = eng.Matrix(rp, ci, a, m, n, fmt, dtype, col_blocks=cb, convert_on=1)
+            assert D.format_name == H.format_name and D.mem_footprint == H.mem_footprint and ("COOB" in H.format_name or "MERGEB" in H.format_name)
+            for k in BLOCKED_ARRAYS:
+                np.testing.assert_array_equal(D.stored_array(k), H.stored_array(k), err_msg=f"{H.format_name} m={m} {k}")
+            # same bytes, same kernel; the kernel's LDS atomics add in no fixed order, so two launches agree to rounding only
+            absrow = oracle.csr_spmv(rp, ci, np.abs(a), np.abs(x))
+            check(D.spmv(x), oracle.csr_spmv(rp, ci, a, x, dtype), absrow, dtype, False, f"{D.format_name} m={m} (GPU-built)")
+            H.close()
+            D.close()
+
+
 def test_beta_accumulate_and_row_blocks(eng, oracle):
     """Row-partitioned use: row blocks reproduce the global y in index order; the local/remote column
     split y = A_loc x + A_rem x (beta = 1) matches the unsplit product."""
@@ -386,6 +420,67 @@ def test_device_conversion_equals_host_conversion(eng, oracle, name):
             np.testing.assert_array_equal(D.spmv(x), H.spmv(x))
             y_ref = oracle.csr_spmv(rp, ci, a, x, dtype, num_threads=1)
             np.testing.assert_array_equal(D.spmv(x), y_ref)           # left-to-right FMA per row: bit-exact
+            H.close()
+            D.close()
+
+
+@pytest.mark.parametrize("name", ["banded8", "banded16", "short_band", "empty_rows"])
+def test_device_window_builder_equals_host_builder(eng, oracle, name):
+    """The LDS-window SELL layout (16-bit window-relative indices; kernels_sell_window.hip) built on the GPU (convert_sell.hip:
+    sell_window_convert_device) holds the same bytes in every stored array as the host builder (build_sell.hip: build_sell_window), for
+    the general and the symmetric-storage variant, and multiplies to the same y."""
+    rng = np.random.default_rng(MANIFEST["seed"] + 6)
+    if name == "banded8":
+        m = 5000
+        rp, ci, a = _banded(rng, m, 40, 9)
+    elif name == "banded16":
+        m = 6001
+        rp, ci, a = _banded(rng, m, 3000, 7)
+    elif name == "short_band":
+        m = 131                                             # two slices and a bit: ragged last slice and last group
+        rp, ci, a = _banded(rng, m, 5, 3)
+    else:
+        m = 4000                                            # a third of the rows empty: the zero slot behind the window
+        rp0, ci0, a0 = _banded(rng, m, 60, 11)
+        keep = rng.uniform(size=m) > 0.33
+        lens = np.where(keep, np.diff(rp0), 0)
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        sel = np.repeat(keep, np.diff(rp0))
+        ci, a = ci0[sel], a0[sel]
+    x = rng.uniform(-1, 1, m)
+    cases = [dict(sell_window=1, sell_split=1), dict(sell_window=1, sell_split=2, sell_group=4), dict(sell_window=1, sell_split=1, sell_group=1)]
+    for dtype in (np.float64, np.float32):
+        for opts in cases:
+            H = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma", dtype, convert_on=2, **opts)
+            D = eng.Matrix(rp, ci, a, m, m, "sell_c_sigma", dtype, convert_on=1, **opts)
+            assert "SELLW" in H.format_name and D.format_name == H.format_name and D.mem_footprint == H.mem_footprint
+            for k in ("groups", "row_of_sorted", "desc", "idx", "val"):
+                np.testing.assert_array_equal(D.stored_array(k), H.stored_array(k), err_msg=f"{name} {opts} {k}")
+            assert H.stored_array("val").size > 0
+            np.testing.assert_array_equal(D.spmv(x), H.spmv(x))
+            check(D.spmv(x), oracle.csr_spmv(rp, ci, a, x, dtype), oracle.csr_spmv(rp, ci, np.abs(a), np.abs(x)), dtype, False, f"{D.format_name} {name}")
+            H.close()
+            D.close()
+    # symmetric storage: the lower triangle in, the window covers the group's own rows (taken from 65 536 stored entries on)
+    if name == "banded8":
+        m = 20000
+        rp, ci, a = _banded(rng, m, 40, 9)
+        rows = np.repeat(np.arange(m), np.diff(rp))
+        low = ci <= rows
+        rpl = np.concatenate([[0], np.cumsum(np.bincount(rows[low], minlength=m))]).astype(np.int32)
+        cil, al = ci[low], a[low]
+        assert rpl[-1] >= 65536
+        x = rng.uniform(-1, 1, m)
+        for dtype in (np.float64, np.float32):
+            H = eng.Matrix(rpl, cil, al, m, m, "sell_c_sigma", dtype, symmetric_input=1, sell_window=1, convert_on=2)
+            D = eng.Matrix(rpl, cil, al, m, m, "sell_c_sigma", dtype, symmetric_input=1, sell_window=1, convert_on=1)
+            assert "SELLWS" in H.format_name and D.format_name == H.format_name and D.mem_footprint == H.mem_footprint
+            for k in ("groups", "row_of_sorted", "desc", "idx", "val"):
+                np.testing.assert_array_equal(D.stored_array(k), H.stored_array(k), err_msg=f"{name} sym {k}")
+            y_ref = oracle.csr_sym_spmv(rpl, cil, al, x, dtype) if hasattr(oracle, "csr_sym_spmv") else None
+            if y_ref is not None:
+                tol = 1e-12 if dtype == np.float64 else 2e-5
+                np.testing.assert_allclose(D.spmv(x), y_ref, rtol=0, atol=tol * 40)
             H.close()
             D.close()
 
