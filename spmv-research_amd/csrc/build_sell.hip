@@ -345,7 +345,7 @@ build_sell_delta(spmv_mi355x_matrix * A, const int * rp, const int * ci, const d
 					}
 				}
 				if (k < maxlen)
-					val[vb + k * C + r] = v;                   // steps past the longest row exist in the index groups only
+					val[vb + sell_pair_pos(k, maxlen, r)] = v;   // steps past the longest row exist in the index groups only
 				const unsigned d = (unsigned) (c - base);
 				if (md == 5)
 				{

@@ -267,7 +267,7 @@ slice_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, cons
 				c = md == 5 ? base + off5 : base;      // padding: value 0 times a column some lane really uses (mode 5: the pattern's, correction 0)
 			cc[u] = md == 5 ? c - (base + off5) : 0;   // mode 5: the correction of this step (0 for a regular lane)
 			if (k < maxlen)                            // steps past the slice's longest row exist in the index groups only
-				val[vb + (long) k * WAVE + lane] = ok ? (T) va[start + k] : (T) 0;
+				val[vb + sell_pair_pos(k, maxlen, lane)] = ok ? (T) va[start + k] : (T) 0;
 			if (md != 4)
 			{
 				if (lane == 0)

@@ -178,6 +178,43 @@ sell_wide_kernel(const int64_t * __restrict__ slice_ptr, const int * __restrict_
 typedef int sell_int4 __attribute__((ext_vector_type(4)));
 typedef unsigned sell_uint2 __attribute__((ext_vector_type(2)));
 
+// VALUES of a slice are stored in PAIRS of steps: a lane's steps 2p and 2p+1 lie side by side — [pair][lane][2] — so that a group of 4
+// steps is TWO 16-byte loads per lane (fp64; global_load_dwordx4) instead of four 8-byte ones. The kernel sits at the issue rate of
+// its vector-memory instructions (4 value loads + 4 gathers per group: with the value loads at half the count the nlpkkt240 twin runs
+// 9 % faster on the same bytes, profiles/r03_sell_value_pairs.txt). The last step of an odd width stands alone, one element per lane
+// (launch.hpp: sell_pair_pos). `vp` = the group's first element + 2 * lane.
+template <typename T, bool NT>
+__device__ __forceinline__ void
+sell_group_values(const T * __restrict__ vp, T (&v)[4])
+{
+	typedef T T2 __attribute__((ext_vector_type(2)));
+	const T2 w0 = ld_stream<NT>(reinterpret_cast<const T2 *>(vp));
+	const T2 w1 = ld_stream<NT>(reinterpret_cast<const T2 *>(vp + 2 * WAVE));
+	v[0] = w0.x;
+	v[1] = w0.y;
+	v[2] = w1.x;
+	v[3] = w1.y;
+}
+
+// the 1..3 real steps of a slice's last group
+template <typename T, bool NT, int NSTEPS>
+__device__ __forceinline__ void
+sell_tail_values(const T * __restrict__ vp, int lane, T (&v)[3])
+{
+	typedef T T2 __attribute__((ext_vector_type(2)));
+	v[1] = v[2] = T(0);
+	if (NSTEPS == 1)
+		v[0] = ld_stream<NT>(vp - lane);
+	else
+	{
+		const T2 w0 = ld_stream<NT>(reinterpret_cast<const T2 *>(vp));
+		v[0] = w0.x;
+		v[1] = w0.y;
+		if (NSTEPS == 3)
+			v[2] = ld_stream<NT>(vp + 2 * WAVE - lane);
+	}
+}
+
 template <typename T, int MODE, bool NT, int NSTEPS = 4>
 __device__ __forceinline__ void
 sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * __restrict__ vp, int lane, const T * __restrict__ x, T & s,
@@ -223,41 +260,25 @@ sell_delta_group(const unsigned char * __restrict__ gp /* uniform */, const T * 
 	}
 	if (NSTEPS == 4)
 	{
-#if defined(SELL_ABL) && SELL_ABL == 2
-		const T v0 = 1, v1 = 1, v2 = 1, v3 = 1;
-#elif defined(SELL_ABL) && SELL_ABL == 3
-		typedef T T2 __attribute__((ext_vector_type(2)));
-		const T2 w0 = ld_stream<NT>(reinterpret_cast<const T2 *>(vp - lane) + lane);
-		const T2 w1 = ld_stream<NT>(reinterpret_cast<const T2 *>(vp - lane + 2 * WAVE) + lane);
-		const T v0 = w0.x, v1 = w0.y, v2 = w1.x, v3 = w1.y;
-#else
-		const T v0 = ld_stream<NT>(vp);
-		const T v1 = ld_stream<NT>(vp + WAVE);
-		const T v2 = ld_stream<NT>(vp + 2 * WAVE);
-		const T v3 = ld_stream<NT>(vp + 3 * WAVE);
-#endif
-#if defined(SELL_ABL) && SELL_ABL == 1
-		const T x0 = (T) c0, x1 = (T) c1, x2 = (T) c2, x3 = (T) c3;
-#else
+		T v[4];
+		sell_group_values<T, NT>(vp, v);
 		const T x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-#endif
-		s = fma_t<T>(v0, x0, s);
-		s = fma_t<T>(v1, x1, s);
-		s = fma_t<T>(v2, x2, s);
-		s = fma_t<T>(v3, x3, s);
+		s = fma_t<T>(v[0], x0, s);
+		s = fma_t<T>(v[1], x1, s);
+		s = fma_t<T>(v[2], x2, s);
+		s = fma_t<T>(v[3], x3, s);
 	}
 	else
 	{
 		// last group of a slice whose width is not a multiple of 4: the value array holds only the real steps
-		const T v0 = ld_stream<NT>(vp);
-		const T v1 = NSTEPS > 1 ? ld_stream<NT>(vp + WAVE) : T(0);
-		const T v2 = NSTEPS > 2 ? ld_stream<NT>(vp + 2 * WAVE) : T(0);
+		T v[3];
+		sell_tail_values<T, NT, NSTEPS>(vp, lane, v);
 		const T x0 = x[c0];
 		const T x1 = NSTEPS > 1 ? x[c1] : T(0);
 		const T x2 = NSTEPS > 2 ? x[c2] : T(0);
-		s = fma_t<T>(v0, x0, s);
-		if (NSTEPS > 1) s = fma_t<T>(v1, x1, s);
-		if (NSTEPS > 2) s = fma_t<T>(v2, x2, s);
+		s = fma_t<T>(v[0], x0, s);
+		if (NSTEPS > 1) s = fma_t<T>(v[1], x1, s);
+		if (NSTEPS > 2) s = fma_t<T>(v[2], x2, s);
 	}
 }
 
@@ -338,8 +359,10 @@ sell_delta_piped(const unsigned char * __restrict__ ip, const T * __restrict__ v
 		sell_delta_load_idx<MODE, NT>(nb, ip + (size_t) gidx(k + 3) * GB, lane);
 		const T * va = vp + (size_t) ga * 4 * WAVE;
 		const T * vb = vp + (size_t) gb * 4 * WAVE;
-		const T a0 = ld_stream<NT>(va), a1 = ld_stream<NT>(va + WAVE), a2 = ld_stream<NT>(va + 2 * WAVE), a3 = ld_stream<NT>(va + 3 * WAVE);
-		const T b0 = ld_stream<NT>(vb), b1 = ld_stream<NT>(vb + WAVE), b2 = ld_stream<NT>(vb + 2 * WAVE), b3 = ld_stream<NT>(vb + 3 * WAVE);
+		T av[4], bv[4];
+		sell_group_values<T, NT>(va, av);
+		sell_group_values<T, NT>(vb, bv);
+		const T a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3], b0 = bv[0], b1 = bv[1], b2 = bv[2], b3 = bv[3];
 		int ca[4], cb[4];
 		sell_delta_cols<MODE>(a, ca);
 		sell_delta_cols<MODE>(b, cb);
@@ -419,42 +442,89 @@ sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ v
 // deltas although it moves 7 % fewer bytes — the wide load of all 64 lanes cost more than the bytes saved.) That load sits in front
 // of the lane's gathers, so it is fetched one pair of groups ahead like the delta words of modes 1 / 2. Same FMAs in the same order
 // as every other mode: bit-identical results. A slice with a row that needs more than 8 bits falls back to modes 1 / 2 / 4.
+// Slices with at most FOUR exception rows (the common case: 5 % of the rows out of line puts 3.2 into a slice on average) take the
+// corrections through the SCALAR cache instead: the 16 bytes behind the bases hold all of them, one s_load brings bases and corrections,
+// and a compare-and-select per exception puts its dword into its lane — no vector-memory instruction at all for the indices, as in modes 0 / 3.
+// (The kernel runs at the issue rate of its vector-memory instructions: the per-lane dword load of the general path is a ninth
+// instruction per group of 4 steps beside 2 value loads and 4 gathers.)
 struct SellDeltaIdx5 {
 	sell_int4 base;                                // wave-uniform
-	unsigned d;                                    // 4 x int8, exception lanes only
+	unsigned d;                                    // 4 x int8, exception lanes only            (general path)
+	sell_int4 corr;                                // corrections of exceptions 0..3, uniform   (scalar path)
 };
 
 // `rank` is 0 for the lanes that are no exception: they load the first exception's corrections (one address for all of them) and drop
 // them. No branch around the load: with one the compiler cannot count what is outstanding and waits for everything at every trip.
-template <bool NT>
+template <bool NT, bool SCALAR>
 __device__ __forceinline__ void
 sell_delta_load_idx5(SellDeltaIdx5 & q, const unsigned char * __restrict__ gp /* uniform */, int rank)
 {
 	q.base = *reinterpret_cast<const sell_int4 *>(gp);
-	q.d = ld_stream<NT>(reinterpret_cast<const unsigned *>(gp + 16) + rank);
+	if constexpr (SCALAR)
+		q.corr = *reinterpret_cast<const sell_int4 *>(gp + 16);
+	else
+		q.d = ld_stream<NT>(reinterpret_cast<const unsigned *>(gp + 16) + rank);
 }
 
+template <bool SCALAR>
 __device__ __forceinline__ void
-sell_delta_cols5(const SellDeltaIdx5 & q, bool ex, int off, int (&c)[4])
+sell_delta_cols5(const SellDeltaIdx5 & q, bool ex, int lane, int off, const int (&xl)[4], int (&c)[4])
 {
-	const int d = ex ? (int) q.d : 0;
+	int d;
+	if constexpr (SCALAR)
+	{
+		// exception j's dword into its lane; slots past the slice's last exception name a lane that is none and hold zeros (a spare lane keeps 0)
+		d = lane == xl[0] ? q.corr.x : 0;
+		d = lane == xl[1] ? q.corr.y : d;
+		d = lane == xl[2] ? q.corr.z : d;
+		d = lane == xl[3] ? q.corr.w : d;
+	}
+	else
+		d = ex ? (int) q.d : 0;
 	c[0] = q.base.x + off + ((d << 24) >> 24);
 	c[1] = q.base.y + off + ((d << 16) >> 24);
 	c[2] = q.base.z + off + ((d << 8) >> 24);
 	c[3] = q.base.w + off + (d >> 24);
 }
 
-template <typename T, bool NT>
-__device__ __forceinline__ T
-sell_delta_slice5(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int width, int lane, const T * __restrict__ x,
-		int g0 = 0, int gs = 1)
+// keeps what was fetched a trip ahead in the trip it was fetched in (sell_pin above)
+template <bool SCALAR>
+__device__ __forceinline__ void
+sell_pin5(SellDeltaIdx5 & q)
 {
-	const int off = ld_stream<NT>(reinterpret_cast<const int *>(ip) + lane);
-	const unsigned long long mask = *reinterpret_cast<const unsigned long long *>(ip + 4 * WAVE);          // uniform: a scalar load
-	ip += 4 * WAVE + 16;
+	if constexpr (SCALAR)
+	{
+		int a = q.corr.x, b = q.corr.y, c = q.corr.z, d = q.corr.w;
+		asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+		q.corr.x = a;
+		q.corr.y = b;
+		q.corr.z = c;
+		q.corr.w = d;
+	}
+	else
+		sell_pin(q.d);
+}
+
+template <typename T, bool NT, bool SCALAR>
+__device__ __forceinline__ T
+sell_delta_slice5_body(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int width, int lane, const T * __restrict__ x,
+		int g0, int gs, unsigned long long mask, int off)
+{
 	const int E = __popcll(mask);
 	const bool ex = (mask >> lane) & 1ull;
 	const int rank = ex ? __popcll(mask & ((1ull << lane) - 1ull)) : 0;
+	int xl[4] = {0, 0, 0, 0};
+	if constexpr (SCALAR)
+	{
+		unsigned long long mm = mask;
+		const int spare = __builtin_ctzll(~mask);                       // a lane that is no exception (at least 48 are not)
+		#pragma unroll
+		for (int j = 0; j < 4; j++)
+		{
+			xl[j] = mm ? __builtin_ctzll(mm) : spare;
+			mm &= mm - 1ull;
+		}
+	}
 	const size_t GB = 16 + ((size_t) E + 3) / 4 * 16;
 	const int groups = (width + 3) / 4;
 	const int rem = width - 4 * (groups - 1);
@@ -466,20 +536,22 @@ sell_delta_slice5(const unsigned char * __restrict__ ip, const T * __restrict__ 
 	if (n > 0)
 	{
 		auto gidx = [&](int k) { return g0 + (k < n ? k : n - 1) * gs; };       // past the end: the last group again (loaded, not used)
-		sell_delta_load_idx5<NT>(a, ip + (size_t) gidx(0) * GB, rank);
-		sell_delta_load_idx5<NT>(b, ip + (size_t) gidx(1) * GB, rank);
+		sell_delta_load_idx5<NT, SCALAR>(a, ip + (size_t) gidx(0) * GB, rank);
+		sell_delta_load_idx5<NT, SCALAR>(b, ip + (size_t) gidx(1) * GB, rank);
 		for (int k = 0; k < n; k += 2)
 		{
 			const int ga = gidx(k), gb = gidx(k + 1);
-			sell_delta_load_idx5<NT>(na, ip + (size_t) gidx(k + 2) * GB, rank);
-			sell_delta_load_idx5<NT>(nb, ip + (size_t) gidx(k + 3) * GB, rank);
+			sell_delta_load_idx5<NT, SCALAR>(na, ip + (size_t) gidx(k + 2) * GB, rank);
+			sell_delta_load_idx5<NT, SCALAR>(nb, ip + (size_t) gidx(k + 3) * GB, rank);
 			const T * va = vp + (size_t) ga * 4 * WAVE;
 			const T * vb = vp + (size_t) gb * 4 * WAVE;
-			const T a0 = ld_stream<NT>(va), a1 = ld_stream<NT>(va + WAVE), a2 = ld_stream<NT>(va + 2 * WAVE), a3 = ld_stream<NT>(va + 3 * WAVE);
-			const T b0 = ld_stream<NT>(vb), b1 = ld_stream<NT>(vb + WAVE), b2 = ld_stream<NT>(vb + 2 * WAVE), b3 = ld_stream<NT>(vb + 3 * WAVE);
+			T av[4], bv[4];
+			sell_group_values<T, NT>(va, av);
+			sell_group_values<T, NT>(vb, bv);
+			const T a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3], b0 = bv[0], b1 = bv[1], b2 = bv[2], b3 = bv[3];
 			int ca[4], cb[4];
-			sell_delta_cols5(a, ex, off, ca);
-			sell_delta_cols5(b, ex, off, cb);
+			sell_delta_cols5<SCALAR>(a, ex, lane, off, xl, ca);
+			sell_delta_cols5<SCALAR>(b, ex, lane, off, xl, cb);
 			const T x0 = x[ca[0]], x1 = x[ca[1]], x2 = x[ca[2]], x3 = x[ca[3]];
 			const T z0 = x[cb[0]], z1 = x[cb[1]], z2 = x[cb[2]], z3 = x[cb[3]];
 			s = fma_t<T>(a0, x0, s);
@@ -493,8 +565,8 @@ sell_delta_slice5(const unsigned char * __restrict__ ip, const T * __restrict__ 
 				s = fma_t<T>(b2, z2, s);
 				s = fma_t<T>(b3, z3, s);
 			}
-			sell_pin(na.d);
-			sell_pin(nb.d);
+			sell_pin5<SCALAR>(na);
+			sell_pin5<SCALAR>(nb);
 			a = na;
 			b = nb;
 		}
@@ -504,13 +576,18 @@ sell_delta_slice5(const unsigned char * __restrict__ ip, const T * __restrict__ 
 	if (rem != 4 && last >= g0 && (last - g0) % gs == 0)
 	{
 		SellDeltaIdx5 q;
-		sell_delta_load_idx5<NT>(q, ip + (size_t) last * GB, rank);
+		sell_delta_load_idx5<NT, SCALAR>(q, ip + (size_t) last * GB, rank);
 		int c[4];
-		sell_delta_cols5(q, ex, off, c);
+		sell_delta_cols5<SCALAR>(q, ex, lane, off, xl, c);
 		const T * vl = vp + (size_t) last * 4 * WAVE;
-		const T v0 = ld_stream<NT>(vl);
-		const T v1 = rem > 1 ? ld_stream<NT>(vl + WAVE) : T(0);
-		const T v2 = rem > 2 ? ld_stream<NT>(vl + 2 * WAVE) : T(0);
+		T tv[3];
+		if (rem == 1)
+			sell_tail_values<T, NT, 1>(vl, lane, tv);
+		else if (rem == 2)
+			sell_tail_values<T, NT, 2>(vl, lane, tv);
+		else
+			sell_tail_values<T, NT, 3>(vl, lane, tv);
+		const T v0 = tv[0], v1 = tv[1], v2 = tv[2];
 		const T x0 = x[c[0]];
 		const T x1 = rem > 1 ? x[c[1]] : T(0);
 		const T x2 = rem > 2 ? x[c[2]] : T(0);
@@ -519,6 +596,19 @@ sell_delta_slice5(const unsigned char * __restrict__ ip, const T * __restrict__ 
 		if (rem > 2) s = fma_t<T>(v2, x2, s);
 	}
 	return s;
+}
+
+template <typename T, bool NT>
+__device__ __forceinline__ T
+sell_delta_slice5(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int width, int lane, const T * __restrict__ x,
+		int g0 = 0, int gs = 1)
+{
+	const int off = ld_stream<NT>(reinterpret_cast<const int *>(ip) + lane);
+	const unsigned long long mask = *reinterpret_cast<const unsigned long long *>(ip + 4 * WAVE);          // uniform: a scalar load
+	ip += 4 * WAVE + 16;
+	if (__popcll(mask) <= 4)
+		return sell_delta_slice5_body<T, NT, true>(ip, vp, width, lane, x, g0, gs, mask, off);
+	return sell_delta_slice5_body<T, NT, false>(ip, vp, width, lane, x, g0, gs, mask, off);
 }
 
 // desc[2*s] = first value element of slice s, desc[2*s+1] = byte offset of its index block | mode (0 .. 5) in the low bits
@@ -540,7 +630,7 @@ sell_delta_kernel(const int64_t * __restrict__ desc, const unsigned char * __res
 	const int64_t v_next = desc[2 * slice + 2];
 	const int mode = (int) (i_word & 7);
 	const unsigned char * ip = idx + (i_word & ~(int64_t) 15);
-	const T * vp = val + v_off + lane;
+	const T * vp = val + v_off + 2 * lane;
 	const int groups = (int) ((v_next - v_off) / WAVE);       // = the slice's width in steps (name kept: passed as `width`)
 	T s;
 	if (mode == 0)
@@ -579,7 +669,7 @@ sell_delta_split_kernel(const int64_t * __restrict__ desc, const unsigned char *
 		return;
 	const int lane = threadIdx.x % WAVE;
 	const int wave = threadIdx.x / WAVE;
-	const int w = wave % S;
+	const int w = __builtin_amdgcn_readfirstlane(wave % S);          // wave-uniform, and the compiler should know: group addresses stay scalar
 	const int slice = __builtin_amdgcn_readfirstlane((int) (tile * SPB + wave / S));
 	T s = 0;
 	if (slice < num_slices)
@@ -589,7 +679,7 @@ sell_delta_split_kernel(const int64_t * __restrict__ desc, const unsigned char *
 		const int64_t v_next = desc[2 * slice + 2];
 		const int mode = (int) (i_word & 7);
 		const unsigned char * ip = idx + (i_word & ~(int64_t) 15);
-		const T * vp = val + v_off + lane;
+		const T * vp = val + v_off + 2 * lane;
 		const int groups = (int) ((v_next - v_off) / WAVE);       // = the slice's width in steps (name kept: passed as `width`)
 		if (mode == 0)
 			s = sell_delta_slice<T, 0, NT>(ip, vp, groups, lane, x, w, S);

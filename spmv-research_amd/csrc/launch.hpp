@@ -88,6 +88,14 @@ sell_modes_off()
 	return e ? atoi(e) & 7 : 0;
 }
 
+// Where value (step k, lane r) of a 64-row slice of the delta layout lies behind the slice's first element: steps in pairs, a lane's steps
+// 2p and 2p+1 side by side (kernels_sell.hip: sell_group_values); the last step of an odd width stands alone, one element per lane.
+__host__ __device__ inline long
+sell_pair_pos(long k, long width, long r)
+{
+	return (k | 1) < width ? (k / 2) * 128 + r * 2 + (k & 1) : (k / 2) * 128 + r;
+}
+
 // CSR -> SELL-64-sigma-delta on the GPU (convert_sell.hip); outputs are device arrays owned by the caller
 int sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
 		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,

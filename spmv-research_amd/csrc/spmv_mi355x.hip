@@ -607,6 +607,20 @@ spmv_mi355x_sell_layout(const spmv_mi355x_matrix * A, long * C_out, long * sigma
 			for (size_t i = 0; i < (size_t) A->sell_nnz_ext; i++)
 				(*val_out)[i] = tmp[i];
 		}
+		if (A->sell_delta)
+		{
+			// the delta layout keeps a lane's steps in pairs (launch.hpp: sell_pair_pos): back to plain column-major
+			std::vector<double> slice;
+			for (long sl = 0; sl < A->sell_slices; sl++)
+			{
+				const int64_t vb = h_desc[2 * sl];
+				const long width = (h_desc[2 * sl + 2] - vb) / 64;
+				slice.assign(*val_out + vb, *val_out + vb + width * 64);
+				for (long k = 0; k < width; k++)
+					for (long r = 0; r < 64; r++)
+						(*val_out)[vb + k * 64 + r] = slice[(size_t) spmv::sell_pair_pos(k, width, r)];
+			}
+		}
 	}
 	if (row_of_sorted_out)
 	{
