@@ -509,7 +509,7 @@ build_sell_window(spmv_mi355x_matrix * A, const int * rp, const int * ci, const 
 			const unsigned short pad = (len > 0 && !sym) ? (unsigned short) (ci[js + len - 1] - lo) : (unsigned short) gw;
 			for (long k = 0; k < width; k++)
 			{
-				val[(size_t) (vb + k * C + r)] = k < len ? va[js + k] : 0.0;
+				val[(size_t) (vb + sellw_val_pos(k, r, A->f32))] = k < len ? va[js + k] : 0.0;
 				idx[(size_t) (ib + (k / 4) * 4 * C + r * 4 + k % 4)] = k < len ? (unsigned short) (ci[js + k] - lo) : pad;
 			}
 		}

@@ -554,7 +554,7 @@ window_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, con
 		for (int u = 0; u < 4; u++)
 		{
 			const long k = k0 + u;
-			val[b + k * WAVE + r] = k < len ? (T) va[js + k] : (T) 0;
+			val[b + sellw_val_pos(k, r, sizeof(T) == 4)] = k < len ? (T) va[js + k] : (T) 0;
 			q[u] = k < len ? (unsigned short) (ci[js + k] - lo) : pad;
 		}
 		*(uint2 *) (idx + b + k0 * WAVE + r * 4) = make_uint2((unsigned) q[0] | (unsigned) q[1] << 16, (unsigned) q[2] | (unsigned) q[3] << 16);

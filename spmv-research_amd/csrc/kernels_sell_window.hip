@@ -9,7 +9,10 @@
 //     the group only (sigma = 64*NS), so the group is a contiguous range of the matrix's rows;
 //   * the group's column window x[lo .. lo+w) is copied into LDS once with coalesced loads and every gather is an LDS read;
 //   * column indices are stored RELATIVE to lo in 16 bits (w <= 65 536), four steps of a lane packed into one 8-byte load:
-//         index group g of a slice:  [64 lanes][4 steps] u16  = 512 bytes;   values: [step][64 lanes]; both padded to 4 steps
+//         index group g of a slice:  [64 lanes][4 steps] u16  = 512 bytes;   both arrays padded to whole groups of 4 steps
+//         values of group g: 16 bytes per lane and load — fp64 [2 pairs][64 lanes][2 steps], fp32 [64 lanes][4 steps]
+//         (launch.hpp: sellw_val_pos): the kernels run at the issue rate of their vector-memory instructions, and a group is
+//         2 + 1 (fp64) or 1 + 1 (fp32) of them instead of 4 + 1 with one value per lane and load
 //     -> sizeof(V) + 2 bytes per stored entry instead of CSR's sizeof(V) + 4 (fp32: 6 instead of 8);
 //   * S waves share a slice when the matrix has too few slices to fill 256 CUs (wave p takes index groups p, p+S, ...; the
 //     partial sums meet in LDS and are added in wave order). With S = 1 a lane walks its row left to right with one FMA per
@@ -32,6 +35,32 @@ struct SellwPair {
 	T a[4], b[4];
 };
 
+// the 4 values of one lane in one group; vp = the group's first element + (16 / sizeof(T)) * lane
+template <typename T, bool NT>
+__device__ __forceinline__ void
+sellw_values(const T * __restrict__ vp, T (&v)[4])
+{
+	if constexpr (sizeof(T) == 8)
+	{
+		typedef T T2 __attribute__((ext_vector_type(2)));
+		const T2 w0 = ld_stream<NT>(reinterpret_cast<const T2 *>(vp));
+		const T2 w1 = ld_stream<NT>(reinterpret_cast<const T2 *>(vp + 2 * WAVE));
+		v[0] = w0.x;
+		v[1] = w0.y;
+		v[2] = w1.x;
+		v[3] = w1.y;
+	}
+	else
+	{
+		typedef T T4 __attribute__((ext_vector_type(4)));
+		const T4 w = ld_stream<NT>(reinterpret_cast<const T4 *>(vp));
+		v[0] = w.x;
+		v[1] = w.y;
+		v[2] = w.z;
+		v[3] = w.w;
+	}
+}
+
 template <typename T, bool NT>
 __device__ __forceinline__ void
 sellw_load2(SellwPair<T> & p, const sellw_uint2 * __restrict__ ip0, const T * __restrict__ vp0, const sellw_uint2 * __restrict__ ip1,
@@ -39,12 +68,8 @@ sellw_load2(SellwPair<T> & p, const sellw_uint2 * __restrict__ ip0, const T * __
 {
 	p.d0 = ld_stream<NT>(ip0);
 	p.d1 = ld_stream<NT>(ip1);
-	#pragma unroll
-	for (int u = 0; u < 4; u++)
-		p.a[u] = ld_stream<NT>(vp0 + u * WAVE);
-	#pragma unroll
-	for (int u = 0; u < 4; u++)
-		p.b[u] = ld_stream<NT>(vp1 + u * WAVE);
+	sellw_values<T, NT>(vp0, p.a);
+	sellw_values<T, NT>(vp1, p.b);
 }
 
 template <typename T>
@@ -68,12 +93,13 @@ __device__ __forceinline__ void
 sellw_group1(const sellw_uint2 * __restrict__ ip, const T * __restrict__ vp, const T * __restrict__ xs, T & s)
 {
 	const sellw_uint2 d = ld_stream<NT>(ip);
-	const T v0 = ld_stream<NT>(vp), v1 = ld_stream<NT>(vp + WAVE), v2 = ld_stream<NT>(vp + 2 * WAVE), v3 = ld_stream<NT>(vp + 3 * WAVE);
+	T v[4];
+	sellw_values<T, NT>(vp, v);
 	const T x0 = xs[d.x & 0xffffu], x1 = xs[d.x >> 16], x2 = xs[d.y & 0xffffu], x3 = xs[d.y >> 16];
-	s = fma_t<T>(v0, x0, s);
-	s = fma_t<T>(v1, x1, s);
-	s = fma_t<T>(v2, x2, s);
-	s = fma_t<T>(v3, x3, s);
+	s = fma_t<T>(v[0], x0, s);
+	s = fma_t<T>(v[1], x1, s);
+	s = fma_t<T>(v[2], x2, s);
+	s = fma_t<T>(v[3], x3, s);
 }
 
 // grp[4*g .. 4*g+3] = first column of the window, its width, first slice, number of slices of group g
@@ -98,7 +124,7 @@ sell_window_kernel(const int * __restrict__ grp, const int64_t * __restrict__ sd
 	const int slice = slice0 + (active ? wave / S : 0);
 	const int64_t v_off = sdesc[2 * slice], i_off = sdesc[2 * slice + 1], v_next = sdesc[2 * slice + 2];
 	const int groups = (int) ((v_next - v_off) / (4 * WAVE));
-	const T * vp = val + v_off + lane;
+	const T * vp = val + v_off + (16 / (int) sizeof(T)) * lane;
 	const sellw_uint2 * ip = reinterpret_cast<const sellw_uint2 *>(idx + i_off) + lane;
 	// the wave's first two index groups are in flight while the window of x is copied into LDS
 	int g = part;
@@ -252,7 +278,7 @@ sell_window_sym_kernel(const int * __restrict__ grp, const int64_t * __restrict_
 	const int slice = slice0 + (active ? wave / S : 0);
 	const int64_t v_off = sdesc[2 * slice], i_off = sdesc[2 * slice + 1], v_next = sdesc[2 * slice + 2];
 	const int groups = (int) ((v_next - v_off) / (4 * WAVE));
-	const T * vp = val + v_off + lane;
+	const T * vp = val + v_off + (16 / (int) sizeof(T)) * lane;
 	const sellw_uint2 * ip = reinterpret_cast<const sellw_uint2 *>(idx + i_off) + lane;
 	const long sorted_row = (long) slice * WAVE + lane;
 	const bool mine = active && sorted_row < m;
@@ -278,12 +304,8 @@ sell_window_sym_kernel(const int * __restrict__ grp, const int64_t * __restrict_
 		{
 			const sellw_uint2 d0 = ld_stream<NT>(ip + (size_t) g * WAVE), d1 = ld_stream<NT>(ip + (size_t) (g + S) * WAVE);
 			T a[4], b[4];
-			#pragma unroll
-			for (int u = 0; u < 4; u++)
-			{
-				a[u] = ld_stream<NT>(vp + (size_t) g * 4 * WAVE + u * WAVE);
-				b[u] = ld_stream<NT>(vp + (size_t) (g + S) * 4 * WAVE + u * WAVE);
-			}
+			sellw_values<T, NT>(vp + (size_t) g * 4 * WAVE, a);
+			sellw_values<T, NT>(vp + (size_t) (g + S) * 4 * WAVE, b);
 			sellw_sym_group<T>(d0, a, xs, ys, me, xi, s);
 			sellw_sym_group<T>(d1, b, xs, ys, me, xi, s);
 		}
@@ -291,9 +313,7 @@ sell_window_sym_kernel(const int * __restrict__ grp, const int64_t * __restrict_
 		{
 			const sellw_uint2 d0 = ld_stream<NT>(ip + (size_t) g * WAVE);
 			T a[4];
-			#pragma unroll
-			for (int u = 0; u < 4; u++)
-				a[u] = ld_stream<NT>(vp + (size_t) g * 4 * WAVE + u * WAVE);
+			sellw_values<T, NT>(vp + (size_t) g * 4 * WAVE, a);
 			sellw_sym_group<T>(d0, a, xs, ys, me, xi, s);
 		}
 		if (mine)

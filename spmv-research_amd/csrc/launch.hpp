@@ -96,6 +96,14 @@ sell_pair_pos(long k, long width, long r)
 	return (k | 1) < width ? (k / 2) * 128 + r * 2 + (k & 1) : (k / 2) * 128 + r;
 }
 
+// ... and of the LDS-window layout, whose slices are padded to whole groups of 4 steps: 16 bytes per lane and load — fp64 as above,
+// fp32 a lane's 4 steps of a group side by side (kernels_sell_window.hip: sellw_values)
+__host__ __device__ inline long
+sellw_val_pos(long k, long r, bool f32)
+{
+	return f32 ? (k / 4) * 256 + r * 4 + (k & 3) : (k / 2) * 128 + r * 2 + (k & 1);
+}
+
 // CSR -> SELL-64-sigma-delta on the GPU (convert_sell.hip); outputs are device arrays owned by the caller
 int sell_delta_convert_device(bool f32, long m, long n_cols, long nnz, long sigma, const int * rp_host, const int * ci_host,
 		const double * va_host, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned char ** d_idx_out, void ** d_val_out,
