@@ -129,6 +129,9 @@ def parse(argv=None):
                     help="extra seconds without launches after the engine has placed the vectors (the driver clears the ballast the one "
                          "walk returned in the background; the settle phase runs through it; profiles/r02_placement.md §6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline handle: no floor / jitter legs, no configs 1-4 (the profiled command of tools/gpu_profiles.sh: every launch of "
+                         "the headline kernel the profiler then sees is this handle's, so its average can be held against roofline.kernel_ms)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--force-multi", action="store_true",
@@ -637,7 +640,7 @@ def main():
         "setup_s": {"generate": round(t_gen, 2), "convert_upload": round(t["convert_s"], 2), "upload_x_place_vectors": round(t["place_s"], 2)},
         "placement": E.placement_info(torch.cuda.current_device()),
     }
-    if workload == "nlpkkt240" and fmt == "sell_c_sigma" and not args.index_modes_off and not args.jitter and args.scale == 1.0:
+    if workload == "nlpkkt240" and fmt == "sell_c_sigma" and not args.index_modes_off and not args.jitter and args.scale == 1.0 and not args.headline_only:
         # the other end of the headline: the same matrix with every index-free mode of the delta layout switched off (8/16-bit deltas per
         # lane and step everywhere) — what a matrix without the twin's translation invariance gets from the format
         os.environ["SPMV_MI355X_SELL_MODES_OFF"] = "7"
@@ -661,7 +664,7 @@ def main():
     del A, t
     want_configs = args.configs == "on" or (args.configs == "auto" and workload == "nlpkkt240" and args.format is None
                                             and args.scale == 1.0 and not args.jitter and not args.index_modes_off)
-    if want_configs:
+    if want_configs and not args.headline_only:
         result["configs"] = run_small_configs(E, torch, H, args)
     print(json.dumps(result), flush=True)
 

@@ -16,3 +16,10 @@ fi
 timeout -k 10 900 python bench.py > gpurun_out/${ROUND}_bench_default.json 2> gpurun_out/${ROUND}_bench_default.err; echo "bench rc=$?"
 rm -rf gpurun_out/${ROUND}_prof_bench
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${ROUND}_prof_bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/${ROUND}_bench_profiled.json 2> gpurun_out/${ROUND}_bench_profiled.err; echo "profiled bench rc=$?"
+cp $(ls -S gpurun_out/${ROUND}_prof_bench/*/*_kernel_stats.csv | head -1) gpurun_out/${ROUND}_bench_kernel_stats.csv
+# the headline handle alone (no floor / jitter legs, no configs; pools without the array search): every launch of the headline kernel the
+# profiler sees is this handle's — the 1000 timed steps, warm-up and settle phase, and the ~80 trial launches of the placement walk — so
+# the kernel's average in the stats can be held against roofline.kernel_ms of the same run
+rm -rf gpurun_out/${ROUND}_prof_headline
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${ROUND}_prof_headline -- python bench.py --headline-only --placement 1 --no-cpu-baseline > gpurun_out/${ROUND}_bench_headline_profiled.json 2> gpurun_out/${ROUND}_bench_headline_profiled.err; echo "profiled headline rc=$?"
+cp $(ls -S gpurun_out/${ROUND}_prof_headline/*/*_kernel_stats.csv | head -1) gpurun_out/${ROUND}_headline_kernel_stats.csv
