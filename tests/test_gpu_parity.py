@@ -870,8 +870,23 @@ def test_placement_moves_index_arrays_safely(eng, oracle):
     ref = np.array([np.dot(a[i * k:(i + 1) * k], x[ci[i * k:(i + 1) * k]]) for i in sample])
     den = np.array([np.dot(np.abs(a[i * k:(i + 1) * k]), np.abs(x[ci[i * k:(i + 1) * k]])) for i in sample])
     assert np.all(np.abs(y[sample] - ref) <= 1e-12 * den)
+    info = eng.placement_info(0)                         # what the one walk of the device found (spmv_mi355x_placement_info)
+    assert info["state"] in ("pools kept", "no contrast: plain allocations") and info["candidates"] >= 1 and info["walked_gib"] <= 64
+    assert (info["pools"] >= 2 and len(info["us_per_pool"]) == info["pools"] and min(info["us_per_pool"]) > 0) or info["pools"] == 0
+    # the same search for a CALLER's vector pair (spmv_mi355x_place_arrays: what bench_multi.py runs for its local part)
+    import torch
+    xo, yo = A.input_vector(), A.output_vector()
+    xo.torch().copy_(torch.from_numpy(x).cuda())
+    A.place_arrays(xo.ptr, yo.ptr)                       # moves arrays, overwrites y
+    A.spmv_device(xo.ptr, yo.ptr, 0, 0)
+    torch.cuda.synchronize()
+    y2 = yo.torch()[:m].cpu().numpy()
+    assert np.all(np.abs(y2[sample] - ref) <= 1e-12 * den) and np.array_equal(y2, y)      # one lane per row: the same FMAs wherever the arrays lie
+    xo.free()
+    yo.free()
     A.close()
     eng.placement_release()
+    assert eng.placement_info(0)["state"] == "no walk"
 
 
 def test_handle_from_a_csr_that_arrives_in_pieces(eng, oracle):
