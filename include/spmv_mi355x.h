@@ -78,7 +78,7 @@ typedef struct {
 	int  col_filter_mode;   /* 0 = keep all, 1 = keep columns inside [col_begin,col_end), 2 = keep columns outside     */
 	int  sell_delta;        /* SELL with 64-row slices: column indices stored as one base per step + 8/16-bit deltas per lane
 	                           where they fit (lossless, bit-identical results): 0 = auto (on when sell_c = 64), 1 = on, 2 = off */
-	int  convert_on;        /* where the layouts with a GPU builder (SELL delta, SELL LDS-window: csrc/convert_sell.hip; the entry arrays of
+	int  convert_on;        /* where the layouts with a GPU builder (SELL plain / delta / LDS-window: csrc/convert_sell.hip; the entry arrays of
 	                           the column-blocked layout: csrc/convert_coo.hip) are built from the CSR: 0 = auto (GPU), 1 = GPU,
 	                           2 = host (OpenMP; kept as the checker — both produce the same bytes)                    */
 	int  symmetric_input;   /* 1 = the CSR arrays hold ONE triangle of a symmetric matrix (KEEP_SYMMETRY builds of the harness:
@@ -288,7 +288,8 @@ const char * spmv_mi355x_partitioned_exchange(const spmv_mi355x_partitioned * P)
 double spmv_mi355x_partitioned_mem_footprint(const spmv_mi355x_partitioned * P);
 
 /* ---- format introspection for parity tests (host copies of the converted arrays) -------------------------- */
-/* One stored array of the LDS-window SELL layout ("val", "idx", "desc", "row_of_sorted", "groups") or of the column-blocked layout
+/* One stored array of the plain SELL layout ("val", "col", "slice_ptr", "row_of_sorted"), of the LDS-window SELL layout ("val", "idx",
+ * "desc", "row_of_sorted", "groups") or of the column-blocked layout
  * ("entries", "val", "batch_base", "batch_ptr", "chunk_ptr", "chunk_row", "wg_rows", "range_row", "range_long", "long_row") exactly as it
  * lies in device memory: a malloc'ed copy (free with spmv_mi355x_free). For the tests that hold the host and the GPU builder of a
  * layout to the same bytes, and for diagnostics. */

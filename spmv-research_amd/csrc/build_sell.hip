@@ -17,6 +17,19 @@ build_sell(spmv_mi355x_matrix * A, const int * rp, const int * ci, const double 
 	const long slices_per_tile = C > WAVE ? 1 : sell_slices_per_tile();
 	const long sigma = A->sell_sigma;
 	const long num_slices = (m + C - 1) / C;
+	if (A->convert_on_device)
+	{
+		// the GPU builder (convert_sell.hip): the same bytes
+		std::vector<int64_t> slice_ptr;
+		if (sell_plain_convert_device(A->f32, m, A->nnz, C, TPR, sigma, rp, ci, va, &A->d_slice_ptr, &A->d_col, &A->d_val, &A->d_row_of_sorted, slice_ptr))
+			return 1;
+		const int64_t nnz_ext = slice_ptr[(size_t) num_slices];
+		A->sell_slices = num_slices;
+		A->sell_nnz_ext = nnz_ext;
+		A->cfg.map = xcd_map_balanced(slice_ptr.data(), num_slices, slices_per_tile, resolve_remap(A->remap, (num_slices + slices_per_tile - 1) / slices_per_tile));
+		A->mem_footprint = (double) (num_slices + 1) * sizeof(int64_t) + (double) nnz_ext * (A->vbytes + 4) + (double) m * 4;
+		return 0;
+	}
 	std::vector<int> row_of_sorted(std::max<long>(m, 1));
 	const long num_windows = (m + sigma - 1) / sigma;
 	#pragma omp parallel for num_threads(spmv::host_threads()) schedule(dynamic, 4)

@@ -676,4 +676,140 @@ sell_window_convert_device(bool f32, long m, long nnz, int NS, bool sym, long ld
 	return 0;
 }
 
+// ---------------------------------------------------------------- the plain column-major layout (build_sell.hip: build_sell; C = 16 / 32 / 64 / 256) on the GPU
+// Same sort; a slice's width is its first row's length (the rows of a sigma window are sorted by length and sigma is a multiple of C),
+// rounded up to the lanes per row; one thread per (slice, row) writes its row column-major, padding = value 0 times the row's last column.
+
+__global__ __launch_bounds__(CV_BLOCK) void
+plain_width_kernel(const int * __restrict__ rp, const int * __restrict__ row_of_sorted, long m, long num_slices, int C, int TPR, int64_t * __restrict__ count)
+{
+	const long sl = (long) blockIdx.x * CV_BLOCK + threadIdx.x;
+	if (sl > num_slices)
+		return;
+	int64_t c = 0;
+	if (sl < num_slices && sl * C < m)
+	{
+		const int o = row_of_sorted[sl * C];
+		const long width = ((long) (rp[o + 1] - rp[o]) + TPR - 1) / TPR * TPR;
+		c = width * C;
+	}
+	count[sl] = c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(CV_BLOCK) void
+plain_fill_kernel(const int * __restrict__ rp, const int * __restrict__ ci, const double * __restrict__ va, const int * __restrict__ row_of_sorted, long m,
+		long num_slices, int C, const int64_t * __restrict__ ptr, int * __restrict__ col, T * __restrict__ val)
+{
+	const long t = (long) blockIdx.x * CV_BLOCK + threadIdx.x;
+	const long sl = t / C;
+	const int r = (int) (t % C);
+	if (sl >= num_slices)
+		return;
+	const int64_t base = ptr[sl];
+	const long width = (ptr[sl + 1] - base) / C;
+	const long i = sl * C + r;
+	long js = 0, len = 0;
+	if (i < m)
+	{
+		const int o = row_of_sorted[i];
+		js = rp[o];
+		len = rp[o + 1] - js;
+	}
+	const int pad_col = len > 0 ? ci[js + len - 1] : 0;
+	for (long k = 0; k < width; k++)
+	{
+		const int64_t p = base + k * C + r;
+		col[p] = k < len ? ci[js + k] : pad_col;
+		val[p] = k < len ? (T) va[js + k] : (T) 0;
+	}
+}
+
+// From HOST arrays. Device outputs owned by the caller on success; slice_ptr_host for the tile map and the sizes.
+int
+sell_plain_convert_device(bool f32, long m, long nnz, int C, int TPR, long sigma, const int * rp_host, const int * ci_host, const double * va_host,
+		int64_t ** d_slice_ptr_out, int ** d_col_out, void ** d_val_out, int ** d_row_of_sorted_out, std::vector<int64_t> & slice_ptr_host)
+{
+	const long num_slices = (m + C - 1) / C;
+	const long num_windows = (m + sigma - 1) / sigma;
+	const size_t vbytes = f32 ? 4 : 8;
+	if (rp_host[0] != 0)
+	{
+		set_error("sell_plain_convert_device: row_ptr must start at 0");
+		return 1;
+	}
+	Scratch tmp, out_guard;
+	int * rp, * ci, * len, * len_sorted, * ids, * win_off;
+	double * va;
+	int64_t * count;
+	if (tmp.get(&rp, (size_t) (m + 1) * 4) || tmp.get(&ci, (size_t) nnz * 4) || tmp.get(&va, (size_t) nnz * 8) || tmp.get(&len, (size_t) m * 4) ||
+	    tmp.get(&len_sorted, (size_t) m * 4) || tmp.get(&ids, (size_t) m * 4) || tmp.get(&win_off, (size_t) (num_windows + 1) * 4) ||
+	    tmp.get(&count, (size_t) (num_slices + 1) * 8))
+		return 1;
+	HIP_TRY(hipMemcpy(rp, rp_host, (size_t) (m + 1) * 4, hipMemcpyHostToDevice));
+	if (nnz)
+	{
+		HIP_TRY(hipMemcpy(ci, ci_host, (size_t) nnz * 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(va, va_host, (size_t) nnz * 8, hipMemcpyHostToDevice));
+	}
+	int * row_of_sorted = nullptr;
+	HIP_TRY(hipMalloc(&row_of_sorted, ((size_t) std::max<long>(m, 1) + STREAM_SLACK) * 4));
+	out_guard.ptrs.push_back(row_of_sorted);
+	HIP_TRY(hipMemset(row_of_sorted, 0, ((size_t) std::max<long>(m, 1) + STREAM_SLACK) * 4));
+	if (m > 0)
+	{
+		hipLaunchKernelGGL(row_length_kernel, dim3((unsigned) ((m + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0, rp, (int) m, len, ids);
+		hipLaunchKernelGGL(window_offsets_kernel, dim3((unsigned) ((num_windows + 1 + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0, m, sigma, num_windows, win_off);
+		HIP_TRY(hipGetLastError());
+		size_t bytes = 0;
+		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, bytes, len, len_sorted, ids, row_of_sorted, (int) m, (int) num_windows, win_off,
+				win_off + 1, 0, 32, (hipStream_t) 0));
+		void * sort_tmp;
+		if (tmp.get(&sort_tmp, bytes))
+			return 1;
+		HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(sort_tmp, bytes, len, len_sorted, ids, row_of_sorted, (int) m, (int) num_windows, win_off,
+				win_off + 1, 0, 32, (hipStream_t) 0));
+	}
+	int64_t * ptr = nullptr;
+	HIP_TRY(hipMalloc(&ptr, ((size_t) num_slices + 1) * 8));
+	out_guard.ptrs.push_back(ptr);
+	hipLaunchKernelGGL(plain_width_kernel, dim3((unsigned) ((num_slices + 1 + CV_BLOCK - 1) / CV_BLOCK)), dim3(CV_BLOCK), 0, 0, rp, row_of_sorted, m, num_slices, C, TPR, count);
+	HIP_TRY(hipGetLastError());
+	{
+		size_t bytes = 0;
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, count, ptr, (int) (num_slices + 1), (hipStream_t) 0));
+		void * scan_tmp;
+		if (tmp.get(&scan_tmp, bytes))
+			return 1;
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, bytes, count, ptr, (int) (num_slices + 1), (hipStream_t) 0));
+	}
+	slice_ptr_host.assign((size_t) num_slices + 1, 0);
+	HIP_TRY(hipMemcpy(slice_ptr_host.data(), ptr, ((size_t) num_slices + 1) * 8, hipMemcpyDeviceToHost));
+	const int64_t nnz_ext = slice_ptr_host[(size_t) num_slices];
+	int * col = nullptr;
+	void * val = nullptr;
+	HIP_TRY(hipMalloc(&col, ((size_t) nnz_ext + STREAM_SLACK) * 4));
+	out_guard.ptrs.push_back(col);
+	HIP_TRY(hipMalloc(&val, ((size_t) nnz_ext + STREAM_SLACK) * vbytes));
+	out_guard.ptrs.push_back(val);
+	HIP_TRY(hipMemset(col + nnz_ext, 0, STREAM_SLACK * 4));
+	HIP_TRY(hipMemset((char *) val + (size_t) nnz_ext * vbytes, 0, STREAM_SLACK * vbytes));
+	if (num_slices > 0)
+	{
+		const unsigned grid = (unsigned) ((num_slices * C + CV_BLOCK - 1) / CV_BLOCK);
+		if (f32)
+			hipLaunchKernelGGL((plain_fill_kernel<float>), dim3(grid), dim3(CV_BLOCK), 0, 0, rp, ci, va, row_of_sorted, m, num_slices, C, ptr, col, (float *) val);
+		else
+			hipLaunchKernelGGL((plain_fill_kernel<double>), dim3(grid), dim3(CV_BLOCK), 0, 0, rp, ci, va, row_of_sorted, m, num_slices, C, ptr, col, (double *) val);
+		HIP_TRY(hipGetLastError());
+	}
+	HIP_TRY(hipDeviceSynchronize());
+	out_guard.ptrs.clear();
+	*d_slice_ptr_out = ptr;
+	*d_col_out = col;
+	*d_val_out = val;
+	*d_row_of_sorted_out = row_of_sorted;
+	return 0;
+}
+
 }  // namespace spmv

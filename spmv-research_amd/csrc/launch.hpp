@@ -118,6 +118,9 @@ int blocked_entries_convert_device(bool f32, bool uniform, long m, long nnz, con
 		const std::vector<int> & range_row, const std::vector<int> & range_long, const std::vector<int> & long_row, const std::vector<int> & chunk_ptr,
 		const std::vector<int> & chunk_row, const std::vector<int> & wg_rows, long SPAN, long BATCH, int slot_bits, int SPARE, long ghost_batches,
 		std::vector<int> & batch_ptr, unsigned ** d_ent_out, void ** d_val_out, int ** d_batch_base_out);
+// CSR -> the plain column-major SELL-C-sigma layout on the GPU (convert_sell.hip)
+int sell_plain_convert_device(bool f32, long m, long nnz, int C, int TPR, long sigma, const int * rp_host, const int * ci_host, const double * va_host,
+		int64_t ** d_slice_ptr_out, int ** d_col_out, void ** d_val_out, int ** d_row_of_sorted_out, std::vector<int64_t> & slice_ptr_host);
 // CSR -> the LDS-window layout on the GPU (convert_sell.hip); 0 = built, 1 = error, 2 = a group's window is too wide
 int sell_window_convert_device(bool f32, long m, long nnz, int NS, bool sym, long lds_budget_bytes, const int * rp_host, const int * ci_host,
 		const double * va_host, int ** d_grp_out, int ** d_row_of_sorted_out, int64_t ** d_desc_out, unsigned short ** d_idx_out, void ** d_val_out,

@@ -468,6 +468,9 @@ spmv_mi355x_stored_array(const spmv_mi355x_matrix * A, const char * name, void *
 		arrs = {{"val", A->d_val, (size_t) A->sell_nnz_ext * A->vbytes}, {"idx", A->d_sell_idx, (size_t) A->sell_idx_bytes},
 		        {"desc", A->d_sell_desc, 2 * ((size_t) A->sell_slices + 1) * 8}, {"row_of_sorted", A->d_row_of_sorted, (size_t) A->m * 4},
 		        {"groups", A->d_sellw_grp, (size_t) A->sellw_groups * 16}};
+	else if (A->format == SPMV_MI355X_SELL_C_SIGMA && !A->sell_delta)
+		arrs = {{"val", A->d_val, (size_t) A->sell_nnz_ext * A->vbytes}, {"col", A->d_col, (size_t) A->sell_nnz_ext * 4},
+		        {"slice_ptr", A->d_slice_ptr, ((size_t) A->sell_slices + 1) * 8}, {"row_of_sorted", A->d_row_of_sorted, (size_t) A->m * 4}};
 	else if (A->d_coob_ent)
 	{
 		const size_t NT = (size_t) A->coob_ranges * spmv::coo_blocked_wgs_per_range(), BATCH = (size_t) spmv::coo_blocked_batch_entries(A->cfg.unit != 0);
@@ -480,7 +483,7 @@ spmv_mi355x_stored_array(const spmv_mi355x_matrix * A, const char * name, void *
 	}
 	else
 	{
-		set_error("stored_array: only for the LDS-window SELL layout and the column-blocked layout (this handle: %s)", A->format_name);
+		set_error("stored_array: only for the plain and the LDS-window SELL layouts and the column-blocked layout (this handle: %s)", A->format_name);
 		return 1;
 	}
 	for (const Arr & a : arrs)

@@ -620,7 +620,9 @@ def run(args, B):
     c.t_dtype = torch.float64 if c.dts == "f64" else torch.float32
     c.vbytes = 8 if c.dts == "f64" else 4
     c.opts = B.collect_opts(args, workload)
-    c.opts.setdefault("placement", getattr(c.args, "placement", 3))        # csrc/placement.hip: opt-in, and the bench opts in (bench.py --placement)
+    # csrc/placement.hip: opt-in, and the bench opts in (bench.py --placement) — unless ranks share a GPU (a gloo rehearsal on one box):
+    # the walks of two processes on one device race for its free memory
+    c.opts.setdefault("placement", getattr(c.args, "placement", 3) if c.world <= torch.cuda.device_count() else 0)
     c.opts.setdefault("placement_budget_gib", 160)
     c.sp = torch.cuda.current_stream().cuda_stream
     t0 = time.time()

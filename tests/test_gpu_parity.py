@@ -254,6 +254,36 @@ def test_blocked_layout_with_several_passes_and_split_rows(eng, oracle, fmt, mon
                 A.close()
 
 
+@pytest.mark.parametrize("name", ["powerlaw", "short", "regular_ragged", "one_row", "empty"])
+def test_device_plain_sell_builder_equals_host_builder(eng, oracle, name):
+    """The plain column-major SELL-C-sigma layout (C = 16 / 32 / 64 / 256: the layout the parity entry points a6' / a7 compare with the
+    reference's) built on the GPU (convert_sell.hip: sell_plain_convert_device) holds the same bytes as the host builder's."""
+    rng = np.random.default_rng(MANIFEST["seed"] + 7)
+    if name == "regular_ragged":
+        m, n = 4099, 257
+        rp, ci, a = synth(rng, m, n, "regular")
+    elif name == "one_row":
+        m, n = 1000, 70000
+    elif name == "empty":
+        m, n = 777, 555
+    else:
+        m = n = 30000
+    if name != "regular_ragged":
+        rp, ci, a = synth(rng, m, n, name)
+    x = rng.uniform(-1, 1, n)
+    for dtype in (np.float64, np.float32):
+        for C_rows, sigma in ((16, 16), (32, 1024), (64, 64), (64, 16384), (256, 16384)):
+            opts = dict(sell_c=C_rows, sell_sigma=sigma, sell_delta=2, sell_window=2)
+            H = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, convert_on=2, **opts)
+            D = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, convert_on=1, **opts)
+            assert D.format_name == H.format_name and D.mem_footprint == H.mem_footprint and "SELLD" not in H.format_name
+            for k in ("slice_ptr", "row_of_sorted", "col", "val"):
+                np.testing.assert_array_equal(D.stored_array(k), H.stored_array(k), err_msg=f"{name} C={C_rows} sigma={sigma} {k}")
+            np.testing.assert_array_equal(D.spmv(x), H.spmv(x))
+            H.close()
+            D.close()
+
+
 BLOCKED_ARRAYS = ("entries", "val", "batch_base", "batch_ptr", "chunk_ptr", "chunk_row", "wg_rows", "range_row", "range_long", "long_row")
 
 
