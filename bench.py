@@ -644,7 +644,7 @@ def main():
         # the other end of the headline: the same matrix with every index-free mode of the delta layout switched off (8/16-bit deltas per
         # lane and step everywhere) — what a matrix without the twin's translation invariance gets from the format
         os.environ["SPMV_MI355X_SELL_MODES_OFF"] = "7"
-        tf = time_handle(E, torch, A, fmt, dts, opts, min(args.steps, 300), args.warmup, x_host=t["x_host"])
+        tf = time_handle(E, torch, A, fmt, dts, opts, min(args.steps, 300), args.warmup, x_host=t["x_host"], windows=windows)
         del os.environ["SPMV_MI355X_SELL_MODES_OFF"]
         rf = roofline_record(workload, dts, tf, with_traffic=False)
         result["roofline"]["frac_floor"] = rf["frac"]
@@ -654,7 +654,7 @@ def main():
         # ... and in between: 5 % of the rows out of line (their off-diagonal columns moved by up to +-3): the slices they sit in keep
         # their lane offsets and carry one signed byte per step for the rows that do not fit (mode 5 of the layout)
         Aj, _ = load_workload(H, workload, args.scale, 0.05, 3)
-        tj = time_handle(E, torch, Aj, fmt, dts, opts, min(args.steps, 300), args.warmup)
+        tj = time_handle(E, torch, Aj, fmt, dts, opts, min(args.steps, 300), args.warmup, windows=windows)
         rj = roofline_record(workload, dts, tj, with_traffic=False)
         result["roofline"]["jitter"] = {"what": "5 % of the rows perturbed by +-3 columns (bench.py --jitter 0.05)", "frac": rj["frac"], "ms": rj["ms"],
                                         "kernel_ms": rj["kernel_ms"], "stored_bytes_per_nnz": round(tj["mem_footprint"] / max(Aj["nnz"], 1), 3)}

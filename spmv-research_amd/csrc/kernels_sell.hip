@@ -411,6 +411,23 @@ sell_delta_slice(const unsigned char * __restrict__ ip, const T * __restrict__ v
 		sell_delta_piped<T, MODE, NT>(ip, vp, lane, x, s, g0, gs, n);
 		g = g0 + n * gs;
 	}
+	// 16, then 12, then 8 steps in flight per trip: a slice of 7 full groups (the nlpkkt240 twin's 27-28 entries per row) is 4 + 3. The
+	// loads of a trip are independent of its FMAs, so the compiler issues all of them first; deeper trips measured 2-3 % faster than
+	// pairs alone on the twin (1 152-1 185 against 1 198-1 207 us, profiles/r03_sell_value_pairs.txt).
+	const int full_end = rem == 4 ? groups : last;
+	for (; g + 3 * gs < full_end; g += 4 * gs)
+	{
+		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
+		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + gs) * GB, vp + (size_t) (g + gs) * 4 * WAVE, lane, x, s, off);
+		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + 2 * gs) * GB, vp + (size_t) (g + 2 * gs) * 4 * WAVE, lane, x, s, off);
+		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + 3 * gs) * GB, vp + (size_t) (g + 3 * gs) * 4 * WAVE, lane, x, s, off);
+	}
+	for (; g + 2 * gs < full_end; g += 3 * gs)
+	{
+		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
+		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + gs) * GB, vp + (size_t) (g + gs) * 4 * WAVE, lane, x, s, off);
+		sell_delta_group<T, MODE, NT>(ip + (size_t) (g + 2 * gs) * GB, vp + (size_t) (g + 2 * gs) * 4 * WAVE, lane, x, s, off);
+	}
 	for (; g + gs < (rem == 4 ? groups : last); g += 2 * gs)    // 8 steps in flight per trip
 	{
 		sell_delta_group<T, MODE, NT>(ip + (size_t) g * GB, vp + (size_t) g * 4 * WAVE, lane, x, s, off);
