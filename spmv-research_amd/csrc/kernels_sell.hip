@@ -16,6 +16,8 @@
 //
 // y is scattered through row_of_sorted (the reference does the same: sell_sorted.cpp:392-395).
 
+#include <type_traits>
+
 #include "launch.hpp"
 
 namespace spmv {
@@ -340,7 +342,35 @@ sell_delta_cols(const SellDeltaIdx<MODE> & q, int (&c)[4])
 	}
 }
 
-// the full 4-step groups number g0, g0+gs, ... (n of them) of a slice in mode 1 / 2, two groups per trip, index words one trip ahead
+// the full 4-step groups number g0, g0+gs, ... (n of them) of a slice in mode 1 / 2: FOUR groups per trip (16 steps in flight: all loads of a
+// trip are issued before its first FMA), their index words fetched one trip ahead; what is left (0..3 groups) as a pair and / or a single
+// group on the index words the last trip already fetched. (Two groups per trip: 1 347 us with every index-free mode off; four: see
+// profiles/r03_sell_value_pairs.txt.)
+template <typename T, int MODE, bool NT, int NG>
+__device__ __forceinline__ void
+sell_delta_consume(const SellDeltaIdx<MODE> * q, const T * __restrict__ vp, const int * g, const T * __restrict__ x, T & s)
+{
+	T v[NG][4];
+	int c[NG][4];
+	T xv[NG][4];
+	#pragma unroll
+	for (int u = 0; u < NG; u++)
+		sell_group_values<T, NT>(vp + (size_t) g[u] * 4 * WAVE, v[u]);
+	#pragma unroll
+	for (int u = 0; u < NG; u++)
+		sell_delta_cols<MODE>(q[u], c[u]);
+	#pragma unroll
+	for (int u = 0; u < NG; u++)
+		#pragma unroll
+		for (int t = 0; t < 4; t++)
+			xv[u][t] = x[c[u][t]];
+	#pragma unroll
+	for (int u = 0; u < NG; u++)
+		#pragma unroll
+		for (int t = 0; t < 4; t++)
+			s = fma_t<T>(v[u][t], xv[u][t], s);
+}
+
 template <typename T, int MODE, bool NT>
 __device__ __forceinline__ void
 sell_delta_piped(const unsigned char * __restrict__ ip, const T * __restrict__ vp, int lane, const T * __restrict__ x, T & s, int g0, int gs, int n)
@@ -349,40 +379,40 @@ sell_delta_piped(const unsigned char * __restrict__ ip, const T * __restrict__ v
 	if (n <= 0)
 		return;
 	auto gidx = [&](int k) { return g0 + (k < n ? k : n - 1) * gs; };       // past the end: the last group again (loaded, not used)
-	SellDeltaIdx<MODE> a, b, na, nb;
-	sell_delta_load_idx<MODE, NT>(a, ip + (size_t) gidx(0) * GB, lane);
-	sell_delta_load_idx<MODE, NT>(b, ip + (size_t) gidx(1) * GB, lane);
-	for (int k = 0; k < n; k += 2)
+	SellDeltaIdx<MODE> q[4], nq[4];
+	#pragma unroll
+	for (int u = 0; u < 4; u++)
+		sell_delta_load_idx<MODE, NT>(q[u], ip + (size_t) gidx(u) * GB, lane);
+	int k = 0;
+	for (; k + 4 <= n; k += 4)
 	{
-		const int ga = gidx(k), gb = gidx(k + 1);
-		sell_delta_load_idx<MODE, NT>(na, ip + (size_t) gidx(k + 2) * GB, lane);
-		sell_delta_load_idx<MODE, NT>(nb, ip + (size_t) gidx(k + 3) * GB, lane);
-		const T * va = vp + (size_t) ga * 4 * WAVE;
-		const T * vb = vp + (size_t) gb * 4 * WAVE;
-		T av[4], bv[4];
-		sell_group_values<T, NT>(va, av);
-		sell_group_values<T, NT>(vb, bv);
-		const T a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3], b0 = bv[0], b1 = bv[1], b2 = bv[2], b3 = bv[3];
-		int ca[4], cb[4];
-		sell_delta_cols<MODE>(a, ca);
-		sell_delta_cols<MODE>(b, cb);
-		const T x0 = x[ca[0]], x1 = x[ca[1]], x2 = x[ca[2]], x3 = x[ca[3]];
-		const T z0 = x[cb[0]], z1 = x[cb[1]], z2 = x[cb[2]], z3 = x[cb[3]];
-		s = fma_t<T>(a0, x0, s);
-		s = fma_t<T>(a1, x1, s);
-		s = fma_t<T>(a2, x2, s);
-		s = fma_t<T>(a3, x3, s);
-		if (k + 1 < n)                               // wave-uniform: an odd count ends on a single group
+		#pragma unroll
+		for (int u = 0; u < 4; u++)
+			sell_delta_load_idx<MODE, NT>(nq[u], ip + (size_t) gidx(k + 4 + u) * GB, lane);
+		const int g[4] = {gidx(k), gidx(k + 1), gidx(k + 2), gidx(k + 3)};
+		sell_delta_consume<T, MODE, NT, 4>(q, vp, g, x, s);
+		#pragma unroll
+		for (int u = 0; u < 4; u++)
 		{
-			s = fma_t<T>(b0, z0, s);
-			s = fma_t<T>(b1, z1, s);
-			s = fma_t<T>(b2, z2, s);
-			s = fma_t<T>(b3, z3, s);
+			sell_pin(nq[u].d, MODE == 2);
+			q[u] = nq[u];
 		}
-		sell_pin(na.d, MODE == 2);
-		sell_pin(nb.d, MODE == 2);
-		a = na;
-		b = nb;
+	}
+	const int r = n - k;                               // 0..3 groups left; q[0..r-1] hold their index words (wave-uniform branches)
+	if (r >= 2)
+	{
+		const int g[2] = {gidx(k), gidx(k + 1)};
+		sell_delta_consume<T, MODE, NT, 2>(q, vp, g, x, s);
+	}
+	if (r == 1)                                        // (constant indices into q: a run-time one would send the array to scratch memory)
+	{
+		const int g[1] = {gidx(k)};
+		sell_delta_consume<T, MODE, NT, 1>(q, vp, g, x, s);
+	}
+	if (r == 3)
+	{
+		const int g[1] = {gidx(k + 2)};
+		sell_delta_consume<T, MODE, NT, 1>(q + 2, vp, g, x, s);
 	}
 }
 
@@ -549,43 +579,67 @@ sell_delta_slice5_body(const unsigned char * __restrict__ ip, const T * __restri
 	const int full = rem == 4 ? groups : last;
 	const int n = full > g0 ? (full - g0 + gs - 1) / gs : 0;     // full groups this wave takes: g0, g0 + gs, ...
 	T s = 0;
-	SellDeltaIdx5 a, b, na, nb;
 	if (n > 0)
 	{
+		// four groups per trip, index words (and corrections) one trip ahead; the 0..3 groups left as a pair and / or a single one
+		// (sell_delta_piped above)
 		auto gidx = [&](int k) { return g0 + (k < n ? k : n - 1) * gs; };       // past the end: the last group again (loaded, not used)
-		sell_delta_load_idx5<NT, SCALAR>(a, ip + (size_t) gidx(0) * GB, rank);
-		sell_delta_load_idx5<NT, SCALAR>(b, ip + (size_t) gidx(1) * GB, rank);
-		for (int k = 0; k < n; k += 2)
+		auto consume = [&](const SellDeltaIdx5 * q, const int * g, auto ng) {
+			constexpr int NG = decltype(ng)::value;
+			T v[NG][4];
+			int c[NG][4];
+			T xv[NG][4];
+			#pragma unroll
+			for (int u = 0; u < NG; u++)
+				sell_group_values<T, NT>(vp + (size_t) g[u] * 4 * WAVE, v[u]);
+			#pragma unroll
+			for (int u = 0; u < NG; u++)
+				sell_delta_cols5<SCALAR>(q[u], ex, lane, off, xl, c[u]);
+			#pragma unroll
+			for (int u = 0; u < NG; u++)
+				#pragma unroll
+				for (int t = 0; t < 4; t++)
+					xv[u][t] = x[c[u][t]];
+			#pragma unroll
+			for (int u = 0; u < NG; u++)
+				#pragma unroll
+				for (int t = 0; t < 4; t++)
+					s = fma_t<T>(v[u][t], xv[u][t], s);
+		};
+		SellDeltaIdx5 q[4], nq[4];
+		#pragma unroll
+		for (int u = 0; u < 4; u++)
+			sell_delta_load_idx5<NT, SCALAR>(q[u], ip + (size_t) gidx(u) * GB, rank);
+		int k = 0;
+		for (; k + 4 <= n; k += 4)
 		{
-			const int ga = gidx(k), gb = gidx(k + 1);
-			sell_delta_load_idx5<NT, SCALAR>(na, ip + (size_t) gidx(k + 2) * GB, rank);
-			sell_delta_load_idx5<NT, SCALAR>(nb, ip + (size_t) gidx(k + 3) * GB, rank);
-			const T * va = vp + (size_t) ga * 4 * WAVE;
-			const T * vb = vp + (size_t) gb * 4 * WAVE;
-			T av[4], bv[4];
-			sell_group_values<T, NT>(va, av);
-			sell_group_values<T, NT>(vb, bv);
-			const T a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3], b0 = bv[0], b1 = bv[1], b2 = bv[2], b3 = bv[3];
-			int ca[4], cb[4];
-			sell_delta_cols5<SCALAR>(a, ex, lane, off, xl, ca);
-			sell_delta_cols5<SCALAR>(b, ex, lane, off, xl, cb);
-			const T x0 = x[ca[0]], x1 = x[ca[1]], x2 = x[ca[2]], x3 = x[ca[3]];
-			const T z0 = x[cb[0]], z1 = x[cb[1]], z2 = x[cb[2]], z3 = x[cb[3]];
-			s = fma_t<T>(a0, x0, s);
-			s = fma_t<T>(a1, x1, s);
-			s = fma_t<T>(a2, x2, s);
-			s = fma_t<T>(a3, x3, s);
-			if (k + 1 < n)                               // wave-uniform: an odd count ends on a single group
+			#pragma unroll
+			for (int u = 0; u < 4; u++)
+				sell_delta_load_idx5<NT, SCALAR>(nq[u], ip + (size_t) gidx(k + 4 + u) * GB, rank);
+			const int g[4] = {gidx(k), gidx(k + 1), gidx(k + 2), gidx(k + 3)};
+			consume(q, g, std::integral_constant<int, 4>());
+			#pragma unroll
+			for (int u = 0; u < 4; u++)
 			{
-				s = fma_t<T>(b0, z0, s);
-				s = fma_t<T>(b1, z1, s);
-				s = fma_t<T>(b2, z2, s);
-				s = fma_t<T>(b3, z3, s);
+				sell_pin5<SCALAR>(nq[u]);
+				q[u] = nq[u];
 			}
-			sell_pin5<SCALAR>(na);
-			sell_pin5<SCALAR>(nb);
-			a = na;
-			b = nb;
+		}
+		const int r = n - k;
+		if (r >= 2)
+		{
+			const int g[2] = {gidx(k), gidx(k + 1)};
+			consume(q, g, std::integral_constant<int, 2>());
+		}
+		if (r == 1)
+		{
+			const int g[1] = {gidx(k)};
+			consume(q, g, std::integral_constant<int, 1>());
+		}
+		if (r == 3)
+		{
+			const int g[1] = {gidx(k + 2)};
+			consume(q + 2, g, std::integral_constant<int, 1>());
 		}
 	}
 	// the last group of a slice whose width is not a multiple of 4 (the value array holds only its `rem` real steps); with several
