@@ -57,6 +57,27 @@ def test_no_cpu_fallback_without_a_device():
         E.Matrix(rp, np.array([0], np.int32), np.array([1.0]), 1, 1, "csr_vector")
 
 
+def test_argument_errors_of_the_entry_points_that_need_no_device():
+    """Entry points added in round 3 reject bad arguments with a message and without touching a device: placement_info /
+    placement_release on a device number out of range, stored_array / place_arrays / output_alloc / input_alloc without a handle."""
+    import spmv_mi355x as E
+    lib = E.lib()
+    st, cand, npool, gib, us = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_long(), (ctypes.c_double * 4)()
+    for dev in (-1, 64, 1000):
+        assert lib.spmv_mi355x_placement_info(ctypes.c_int(dev), ctypes.byref(st), ctypes.byref(cand), ctypes.byref(gib), ctypes.byref(npool), us) == 1
+        assert b"placement_info" in lib.spmv_mi355x_last_error()
+    info = E.placement_info(0)                           # no walk was made in this process: a query, not an action
+    assert info == dict(state="no walk", candidates=0, walked_gib=0, pools=0, us_per_pool=[])
+    assert lib.spmv_mi355x_placement_release(ctypes.c_int(-1)) == 0          # nothing to release: fine
+    out, nb = ctypes.c_void_p(), ctypes.c_size_t()
+    assert lib.spmv_mi355x_stored_array(None, b"val", ctypes.byref(out), ctypes.byref(nb)) == 1
+    assert b"stored_array" in lib.spmv_mi355x_last_error() and out.value is None
+    assert lib.spmv_mi355x_place_arrays(None, None, None) == 1 and b"place_arrays" in lib.spmv_mi355x_last_error()
+    assert lib.spmv_mi355x_output_alloc(None, ctypes.c_size_t(64), ctypes.byref(out)) == 1 and b"output_alloc" in lib.spmv_mi355x_last_error()
+    assert lib.spmv_mi355x_input_alloc(None, ctypes.c_size_t(64), ctypes.byref(out)) == 1 and b"input_alloc" in lib.spmv_mi355x_last_error()
+    assert lib.spmv_mi355x_output_free(None) == 0                            # free(NULL)
+
+
 def test_product_does_not_reference_the_oracle():
     """The oracle is test infrastructure: nothing under spmv-research_amd/ may include, link or import it."""
     pkg = os.path.join(ROOT, "spmv-research_amd")
