@@ -27,11 +27,13 @@ when profiles/traffic_*.json holds a record taken with these kernel sources and 
 headline with every index-free mode of the format switched off (what a matrix without the twin's translation invariance gets).
 
 Order of events at N = 1 (everything before the timed steps is reported under setup_s, none of it is timed): generate the twin ->
-convert (GPU) -> first use of the handle's own x / y: bench.py asks for engine-placed vectors (opts.placement = 1): the first handle
-of the process walks the device's free memory once for two vector pools in blocks of different class, every handle then takes its
-vectors from the pool its kernel runs faster in (csrc/placement.hip; worth up to 13 % on this device, profiles/r02_placement.md)
+convert (GPU) -> first use of the handle's own x / y: bench.py asks for engine-placed vectors (--placement: opts.placement = 3 for
+the headline handle, 1 for the small configs): the first handle of the process walks the device's free memory once for two to four
+vector pools in regions of different class, every handle then takes its vectors from the pool its kernel runs fastest in, and level 3
+also moves a matrix array the driver laid across two regions (csrc/placement.hip; worth 13-17 % on this device,
+profiles/r02_placement.md, profiles/r03_placement_walk.txt; what the walk found is reported as "placement")
 -> W warm-up launches -> settle (batches until two agree within 0.5 %, >= 500 launches; the reference driver warms GPU kernels
-with 1000 calls) -> EXACTLY K timed launches between HIP events, inside a synchronize bracket (K = 1000 by default: 1.3 s of the
+with 1000 calls) -> EXACTLY K timed launches between HIP events, inside a synchronize bracket (K = 1000 by default: 1.2 s of the
 headline kernel; with K < 200 five such windows are timed and the median one is reported with the spread).
 """
 import argparse
