@@ -454,6 +454,67 @@ def test_device_conversion_equals_host_conversion(eng, oracle, name):
             D.close()
 
 
+@pytest.mark.parametrize("kind", ["affine", "lane_offsets", "exceptions", "delta8", "delta16", "int32"])
+def test_every_index_mode_at_every_width(eng, oracle, kind):
+    """The delta layout keeps a lane's values in PAIRS of steps (kernels_sell.hip: sell_group_values; the last step of an odd width stands
+    alone) and walks 16 / 12 / 8 / 4 steps per trip: every index mode of the layout at every slice width 1 .. 19 (all residues mod 4, trips
+    of 4 + 3 + 2 + 1 groups and the 1 - 3 step tail), one and several waves per slice, fp64 and fp32 — the mode is really the one meant
+    (index bytes per group of 4 steps), host and GPU builder give the same bytes, and y is bit-identical to the sequential CPU kernel
+    with one wave per slice."""
+    rng = np.random.default_rng(23)
+    m, n = 320, 2_000_000                                 # five slices
+    want = dict(affine=16, lane_offsets=16, delta8=272, delta16=528, int32=1024)
+    for w in range(1, 20):
+        if kind == "affine":
+            first = np.arange(m, dtype=np.int64) + 7
+            steps = np.sort(rng.choice(np.arange(0, 4000), w, replace=False))
+            cols = first[:, None] + steps[None, :]
+        elif kind in ("lane_offsets", "exceptions"):
+            first = np.repeat(np.arange(m // 64) * 20000, 64) + np.tile(rng.permutation(64) * 3, m // 64) + 11
+            steps = np.sort(rng.choice(np.arange(0, 4000), w, replace=False)) * 200
+            cols = first[:, None] + steps[None, :]
+            if kind == "exceptions" and w > 1:
+                for r in (5, 70, 71, 200):                 # a few rows out of line by a column or two on the later steps
+                    cols[r, 1:] += rng.integers(1, 3, w - 1).cumsum() % 3 + 1 if w > 1 else 0
+        else:
+            span = dict(delta8=250, delta16=60000, int32=n - 10)[kind]
+            base = np.repeat(rng.integers(0, n - span - 1, m // 64), 64)
+            cols = np.sort(np.stack([rng.choice(span, w, replace=False) for _ in range(m)]), axis=1) + base[:, None]
+        cols = np.sort(cols, axis=1)
+        assert np.all(np.diff(cols, axis=1) > 0) if w > 1 else True
+        rp = (np.arange(m + 1) * w).astype(np.int32)
+        ci = cols.reshape(-1).astype(np.int32)
+        a = rng.uniform(-1, 1, m * w)
+        x = rng.uniform(-1, 1, n)
+        for dtype in (np.float64, np.float32):
+            vb = np.dtype(dtype).itemsize
+            y_ref = oracle.csr_spmv(rp, ci, a, x, dtype, num_threads=1)
+            H = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=64, sell_split=1, sell_window=2, convert_on=2)
+            D = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=64, sell_split=1, sell_window=2, convert_on=1)
+            assert D.mem_footprint == H.mem_footprint
+            groups = (w + 3) // 4
+            idx_bytes = H.mem_footprint - (m // 64 + 1) * 16 - m * w * vb - m * 4
+            per_group = (idx_bytes / (m // 64) - (256 if kind == "lane_offsets" else 0)) / groups
+            if kind == "exceptions":
+                if groups >= 2:                            # three slices hold rows out of line: mode 5 (272 B + 32 B per group) beats 8-bit deltas (272 B per group)
+                    assert idx_bytes == 3 * (272 + 32 * groups) + 2 * (256 + 16 * groups), (w, idx_bytes)
+            elif w > 1:                                    # (a one-step slice is a lane-offset slice whatever its columns: 256 + 16 bytes)
+                assert abs(per_group - want[kind]) < 1e-9 or (kind in ("delta8", "delta16") and per_group <= want[kind]), (kind, w, per_group)
+            lh, ld = H.sell_layout(), D.sell_layout()
+            for k in ("slice_ptr", "col", "val", "row_of_sorted"):
+                np.testing.assert_array_equal(ld[k], lh[k], err_msg=f"{kind} w={w} {k}")
+            np.testing.assert_array_equal(ld["col"].reshape(-1, 64)[:w * (m // 64)].reshape(m // 64, w, 64).transpose(0, 2, 1).reshape(m, w), cols)
+            np.testing.assert_array_equal(D.spmv(x), y_ref, err_msg=f"{kind} w={w} {dtype.__name__}")
+            np.testing.assert_array_equal(H.spmv(x), y_ref)
+            H.close()
+            D.close()
+            absrow = oracle.csr_spmv(rp, ci, np.abs(a), np.abs(x))
+            for split in (2, 4):
+                S = eng.Matrix(rp, ci, a, m, n, "sell_c_sigma", dtype, sell_c=64, sell_delta=1, sell_sigma=64, sell_split=split, sell_window=2)
+                check(S.spmv(x), y_ref, absrow, dtype, False, f"{S.format_name} {kind} w={w}")
+                S.close()
+
+
 @pytest.mark.parametrize("name", ["banded8", "banded16", "short_band", "empty_rows"])
 def test_device_window_builder_equals_host_builder(eng, oracle, name):
     """The LDS-window SELL layout (16-bit window-relative indices; kernels_sell_window.hip) built on the GPU (convert_sell.hip:
