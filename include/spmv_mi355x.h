@@ -105,9 +105,9 @@ typedef struct {
 	                           operations in the same order -> bit-identical to it                                             */
 	int  sell_group;        /* sell_window: slices per workgroup (1, 2, 4, 8 or 16; times sell_split at most 16 wavefronts); 0 = auto */
 	int  placement;         /* where the handle's vectors live relative to its value array ("vectors placed by the engine" below):
-	                           0 = off (default: plain allocations), 1 = on (slices of the device's two vector pools; the first handle
+	                           0 = off (default: plain allocations), 1 = on (slices of the device's vector pools; the first handle
 	                           of a process that asks makes ONE walk through the device's free memory to find them), 2 = off,
-	                           3 = 1 + a search over the handle's matrix arrays (worth 1-2 %, ~500 launches).
+	                           3 = 1 + a search over the handle's matrix arrays (worth 1-5 %, ~500 launches).
 	                           SPMV_MI355X_PLACEMENT in the environment overrides: 0 off, 1 on, 2 on + log on stderr, 3, 4 (diagnostic) */
 	int  placement_budget_gib;  /* transient memory the walk may hold, GiB (0 = 160; it never takes the device's last 8 GiB)             */
 } spmv_mi355x_opts;

@@ -1,4 +1,4 @@
-// Placement of the vectors beside the matrix in HBM: two process-wide VECTOR POOLS per device, in blocks of different class.
+// Placement of the vectors beside the matrix in HBM: two to four process-wide VECTOR POOLS per device, in blocks of different class.
 //
 // Measured on MI355X (profiles/r02_placement.md): the 288 GiB of a device behave as 32 GiB blocks that fall into classes, and the
 // SAME SpMV kernel on the SAME matrix and x takes 1.25-1.29 ms or 1.46 ms (nlpkkt240 twin) depending only on whether y sits in
@@ -19,7 +19,9 @@
 // guard returns ballast and rejected candidates on every way out. Other processes on the same GPU: the walk's free-memory
 // check (hipMemGetInfo, then hipMalloc) is racy between processes, and a neighbour's kernels run a few % slower for the seconds
 // the driver takes to clear the returned ballast — one more reason why this is opt-in.
-// Level 3 (SPMV_MI355X_PLACEMENT=3 / opts.placement = 3) adds round 2's search over the handle's matrix arrays (worth 1-2 %).
+// Level 3 (SPMV_MI355X_PLACEMENT=3 / opts.placement = 3; spmv_mi355x_place_arrays for a caller's vectors) adds round 2's search over the handle's
+// matrix arrays — worth 1-5 %: most where the driver laid the value array across two regions, so that no pool is good for y — and places the vectors again
+// when an array moved.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
